@@ -1,0 +1,52 @@
+# Builds, in-tree:
+#   volume-renderer_amd/lib/libvolly_gpu.so    HIP kernels + C-ABI (gfx950)
+#   volume-renderer_amd/lib/libvolly_host.so   host scene pipeline (C++17)
+#   oracle/libvolly_oracle.so                  CPU oracle (test infrastructure)
+#   oracle/_ref/libtricube_ref.so              reference triangleCube.c, only when /root/reference exists
+# Float semantics: the reference is built without FMA and without fast-math
+# (reference Makefile:3), so every target uses -ffp-contract=off.
+
+PKG      := volume-renderer_amd
+LIBDIR   := $(PKG)/lib
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+CC       ?= gcc
+REF      ?= /root/reference
+
+HOST_SRC := $(PKG)/host/mesh.cpp $(PKG)/host/voxelize.cpp $(PKG)/host/tricube.cpp \
+            $(PKG)/host/svo.cpp $(PKG)/host/camera.cpp $(PKG)/host/volly_host_c.cpp
+HOST_HDR := $(PKG)/host/volly_scene.h $(PKG)/host/vollymath.h $(PKG)/host/tricube.h include/volly_host.h include/volly_gpu.h
+
+FPFLAGS  := -ffp-contract=off -fno-fast-math
+
+all: gpu host oracle ref
+
+gpu: $(LIBDIR)/libvolly_gpu.so
+host: $(LIBDIR)/libvolly_host.so
+oracle: oracle/libvolly_oracle.so
+
+$(LIBDIR)/libvolly_gpu.so: $(PKG)/csrc/volly_gpu.hip $(PKG)/csrc/volly_kernels.h include/volly_gpu.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(FPFLAGS) -Iinclude \
+	    -o $@ $(PKG)/csrc/volly_gpu.hip
+
+$(LIBDIR)/libvolly_host.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(LIBDIR)
+	$(CXX) -O2 -std=c++17 -fPIC -shared -pthread $(FPFLAGS) -Wall -Wextra -o $@ $(HOST_SRC)
+
+oracle/libvolly_oracle.so: oracle/volly_oracle.c oracle/volly_oracle.h include/volly_gpu.h
+	$(CC) -O3 -mavx -std=gnu11 -fPIC -shared -fopenmp $(FPFLAGS) -Wall -Wextra -o $@ oracle/volly_oracle.c -lm
+
+# the one reference source that compiles stand-alone (as C++: it includes <cmath>)
+ref:
+	@if [ -f $(REF)/triangleCube.c ]; then $(MAKE) oracle/_ref/libtricube_ref.so; \
+	 else echo "no $(REF): keeping prebuilt oracle/_ref (if any)"; fi
+
+oracle/_ref/libtricube_ref.so: oracle/tricube_ref_export.cpp $(REF)/triangleCube.c
+	@mkdir -p oracle/_ref
+	$(CXX) -O3 -mavx -std=c++14 -fPIC -shared $(FPFLAGS) -I$(REF) -o $@ oracle/tricube_ref_export.cpp
+
+clean:
+	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref
+
+.PHONY: all gpu host oracle ref clean

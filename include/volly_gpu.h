@@ -1,0 +1,182 @@
+/*
+ * volly_gpu.h -- C-ABI of the MI355X (gfx950) primary-ray traversal path.
+ *
+ * This is the drop-in boundary for the per-frame render loop of
+ * dylan-mcleod/Volume-Renderer.  Nothing like it exists in the reference (it is
+ * one C++ translation unit driving everything through C++ objects); every entry
+ * point below names the reference code it replaces as file:line into the
+ * reference tree.
+ *
+ * Conventions
+ *   - plain C types only; inputs are borrowed for the duration of the call,
+ *     outputs are caller allocated;
+ *   - every function returns 0 on success or a negative VOLLY_E_* code, and
+ *     leaves a message retrievable with volly_gpu_last_error() (thread local);
+ *   - one scene handle is bound to one GPU; calls on one handle are not
+ *     re-entrant (the reference is single threaded), different handles may be
+ *     driven from different host threads / processes (one per GPU).
+ */
+#ifndef VOLLY_GPU_H
+#define VOLLY_GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOLLY_OK            0
+#define VOLLY_E_ARG        -1   /* bad argument (null pointer, bad size, bad mode)          */
+#define VOLLY_E_HIP        -2   /* a HIP runtime call failed (message has hipGetErrorString) */
+#define VOLLY_E_NOMEM      -3   /* device or host allocation failed                          */
+#define VOLLY_E_UNSUPPORTED -4  /* e.g. beam mode on a scene uploaded without a low grid     */
+
+#define VOLLY_MISS_INDEX 0xFFFFFFFFu
+
+/* frame flags */
+#define VOLLY_FRAME_BEAM   0    /* raycast_beamOpt, main.cpp:163-166,260 (the live path)      */
+#define VOLLY_FRAME_NAIVE  1    /* raycast_naiive_vec4 from camPos_Local, main.cpp:261        */
+
+typedef struct volly_gpu_scene volly_gpu_scene;   /* opaque, owns device memory */
+
+/* Dense grid = VolumeStore<Voxel> (volume.h:56-93): sx*sy*sz voxels of 8 bytes
+ * (voxel.h:13-16: r,g,b,a,nx,ny,nz,nw), x fastest: idx = x + sx*(y + sy*z)
+ * (volume.h:79-81).  A voxel is empty iff a == 0 (main.cpp:140). */
+typedef struct {
+    int32_t     sx, sy, sz;
+    const void *voxels;
+} volly_dense_desc;
+
+/* One octree node, 8 bytes.  Flattened, pointer-free form of SVO_Voxel
+ * (svo.h:22-30: valid_mask, leaf_mask and the 32-bit "countour" field that the
+ * reference comments it uses "as the child pointer for now").
+ *   children of a node are stored contiguously, only the valid ones, in octant
+ *   order; octant bit = x | y<<1 | z<<2 of the child's position inside the node;
+ *   child i lives at child_offset + popcount(valid_mask & ((1<<i)-1))
+ *     - in nodes[]  when bit i of leaf_mask is clear,
+ *     - in leaves[] when bit i of leaf_mask is set (children of size 1 voxel).
+ * nodes[0] is the root and covers [0, 2^depth)^3. */
+typedef struct {
+    uint32_t child_offset;
+    uint8_t  valid_mask;
+    uint8_t  leaf_mask;
+    uint16_t pad;
+} volly_svo_node;
+
+/* SparseVoxelOctree (svo.h:33-39, svo.cpp:14-19: maxScale = ceil(log2(res))). */
+typedef struct {
+    uint32_t              n_nodes;
+    uint32_t              n_leaves;
+    int32_t               depth;     /* maxScale: root cell is 2^depth voxels wide          */
+    int32_t               res;       /* grid is res^3, res <= 2^depth                        */
+    const volly_svo_node *nodes;     /* n_nodes  * 8 B                                       */
+    const void           *leaves;    /* n_leaves * 8 B, Voxel payload (voxel.h:13-16)        */
+} volly_svo_desc;
+
+/* Per-frame constants, exactly the values State::raycastOntoScreen computes once
+ * per frame before its pixel loop (main.cpp:201-249).  They are computed on the
+ * host (volly_host: volly_frame_from_camera) and cross the boundary as values. */
+typedef struct {
+    float   row0_hi[4], xdiff_hi[4], ydiff_hi[4];   /* curYLoop, xdiff, ydiff          main.cpp:219-221,232 */
+    float   row0_lo[4], xdiff_lo[4], ydiff_lo[4];   /* curYLooplowp, xdifflowp, ydifflowp  main.cpp:241-244 */
+    float   origin_lo[4];                           /* camPos_Local_lowP               main.cpp:247-249 */
+    float   origin_hi[4];                           /* camPos_Local                    main.cpp:228-230 */
+    float   scale_lo_to_hi[4];                      /* scaleLowptoHighp                main.cpp:239     */
+    int32_t width, height;                          /* renderTargetSizeX/Y             main.h:112       */
+    int32_t x0, y0, tile_w, tile_h;                 /* sub-rectangle rendered by this call (multi-GPU row bands) */
+    int32_t flags;                                  /* VOLLY_FRAME_BEAM / VOLLY_FRAME_NAIVE */
+    int32_t reserved;
+} volly_frame_desc;
+
+/* Output planes.  Each plane holds n_frames * tile_w * tile_h elements, frame
+ * major, then row major inside the sub-rectangle: (x-x0) + (y-y0)*tile_w, which
+ * for a full frame is the reference's data_stream[x + y*W] (main.cpp:269).
+ * Any pointer may be NULL (plane not wanted).
+ *   rgba8     bytes in memory [255, r', g', b'] = glm::u8vec4(255, r*L, g*L, b*L)  main.cpp:269-271
+ *   hit_index x + sx*(y + sy*z) of the hit voxel (uint32 arithmetic), VOLLY_MISS_INDEX on a miss
+ *   steps_lo  number of executions of the sample at main.cpp:137 in the low-grid pass (0 in NAIVE mode)
+ *   steps_hi  same for the target-grid pass; for an SVO target: number of traversal iterations
+ *   depth     dot(ptEnd - origin_hi, direction), evaluated (dx*vx + dy*vy) + dz*vz unfused; +inf on a miss */
+typedef struct {
+    uint32_t *rgba8;
+    uint32_t *hit_index;
+    uint32_t *steps_lo;
+    uint32_t *steps_hi;
+    float    *depth;
+} volly_outputs;
+
+/* Upload the target grid (State::getCurVol(), main.h:118) and the beam grid
+ * (State::getCurVol_LowLOD() = Vol_LOD_Set::arr[1], main.h:119) once, after
+ * State::initAllVolumes (main.cpp:369-387).  `low` may be NULL: the scene then
+ * only renders VOLLY_FRAME_NAIVE frames. */
+int volume_gpu_upload(int device, const volly_dense_desc *target, const volly_dense_desc *low,
+                      volly_gpu_scene **out);
+
+/* Same with the target held as an octree: the GPU-resident form of
+ * SparseVoxelOctree (svo.h:33-39).  `low` as above. */
+int svo_gpu_upload(int device, const volly_svo_desc *svo, const volly_dense_desc *low,
+                   volly_gpu_scene **out);
+
+/* Synthetic dense scene generated on the device (no reference counterpart; it
+ * plays the role of VolumeStore::fillSphere, volume.h:95-111, "so we can test
+ * without access to files"): voxel (x,y,z) is filled iff
+ * volly_noise_hash(x,y,z,seed) < threshold, rgba = 255, norm = hash bits.
+ * The low grid (res/4)^3 marks a cell filled iff any of its 4^3 voxels is.
+ * The exact hash is volly_noise_hash() below. */
+int volume_gpu_generate_noise(int device, int32_t res, uint32_t seed, uint32_t threshold,
+                              volly_gpu_scene **out);
+
+/* Replaces the pixel loop of State::raycastOntoScreen (main.cpp:251-287) for
+ * n_frames frames (all with the same tile_w x tile_h).  Synchronous; planes in
+ * `outs` are HOST pointers (e.g. Texture_SDL::data_stream, main.h:33). */
+int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames,
+                      const volly_outputs *outs);
+
+/* Same, planes in `outs` are DEVICE pointers on the scene's GPU; work is queued
+ * on `hip_stream` (a hipStream_t, NULL = default stream) and the call returns
+ * without waiting.  `frames` is consumed before the call returns. */
+int volume_gpu_render_device(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames,
+                             const volly_outputs *outs, void *hip_stream);
+
+/* Kernel timing with HIP events on the stream the kernels are launched on.
+ * While enabled every traversal-kernel launch is bracketed by an event pair;
+ * volly_gpu_kernel_time waits for them, returns the summed milliseconds and the
+ * number of launches since the last query, and forgets them. */
+int volly_gpu_set_profiling(volly_gpu_scene *scene, int enabled);
+int volly_gpu_kernel_time(volly_gpu_scene *scene, double *ms_total, int *launches);
+
+/* Copy `count` voxels (8 B each) of the target dense grid starting at linear
+ * index `first` back to the host (checks of generated / uploaded scenes). */
+int volly_gpu_read_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count, void *out);
+
+/* Scene facts: 0 sx, 1 sy, 2 sz, 3 is_svo, 4 has_low, 5 low sx, 6 device,
+ * 7 device bytes held (MiB). */
+int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
+
+void        volly_gpu_free(volly_gpu_scene *scene);
+const char *volly_gpu_last_error(void);
+int         volly_gpu_abi_version(void);
+
+/* The integer mix behind volume_gpu_generate_noise, usable on host and device. */
+#if defined(__HIPCC__)
+#define VOLLY_HD __host__ __device__
+#else
+#define VOLLY_HD
+#endif
+VOLLY_HD static inline uint32_t volly_noise_hash(uint32_t x, uint32_t y, uint32_t z, uint32_t seed)
+{
+    uint32_t h = seed * 0x9E3779B1u + x * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h += y * 0xC2B2AE3Du;
+    h ^= h >> 13; h *= 0x297A2D39u;
+    h += z * 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x165667B1u;
+    h ^= h >> 15;
+    return h;
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLLY_GPU_H */

@@ -1,0 +1,251 @@
+"""GPU parity: the HIP path, called through the C-ABI (ctypes over libvolly_gpu.so),
+against the CPU oracle on the same inputs.  Bar: hit index, step counts, depth
+(bit pattern) and rgba8 all bit-exact -- tighter than the 1/255 the north star
+allows for the colour."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, MISS, assert_planes_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(ora, frame, scene, kind):
+    if kind == "dense":
+        return ora.render_frame(frame, low=scene.low, target=scene.target)
+    return ora.render_frame(frame, low=scene.low, svo=scene.svo)
+
+
+def _upload(vra, scene, kind):
+    if kind == "dense":
+        return vra.GpuScene.upload_dense(scene.target, scene.low)
+    return vra.GpuScene.upload_svo(scene.svo, scene.low)
+
+
+def _sizes(scene):
+    lo = scene.low
+    if scene.target is not None:
+        t = scene.target
+        hi = (t.sx, t.sy, t.sz)
+    else:
+        hi = (scene.svo.res,) * 3
+    return hi, (lo.sx, lo.sy, lo.sz)
+
+
+@pytest.mark.parametrize("kind", ["dense", "svo"])
+@pytest.mark.parametrize("naive", [False, True])
+def test_teapot64_views(vra, ora, teapot64, kind, naive):
+    hi, lo = _sizes(teapot64)
+    gpu = _upload(vra, teapot64, kind)
+    frames = vra.orbit_frames(range(0, 16, 3), 16, hi, lo, 160, 120, radius=1.0, naive=naive)
+    got = gpu.render(frames)
+    total_hits = 0
+    for i, f in enumerate(frames):
+        want = _oracle(ora, f, teapot64, kind)
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"{kind} naive={naive} view {i}")
+        total_hits += int((want["hit_index"] != MISS).sum())
+    assert total_hits > 1000
+    gpu.close()
+
+
+@pytest.mark.parametrize("kind", ["dense", "svo"])
+def test_sphere_inside_and_odd_sizes(vra, ora, sphere64, kind):
+    """fillSphere scene (volume.h:95-111); frame sizes that are not multiples of
+    the 32x8 block or the 8x8 tile; camera inside the volume."""
+    hi, lo = _sizes(sphere64)
+    gpu = _upload(vra, sphere64, kind)
+    for (w, h), pos in [((37, 19), (0.1, 0.1, 0.1)), ((8, 8), (1.4, 0.3, 0.6)), ((1, 1), (0.5, -0.7, 0.5)),
+                        ((131, 7), (0.5, 0.5, 0.5))]:
+        view = vra.look_at((0, 0, 0), vra.host.cam_dir_from_mouse(300, 500), (0, 0, -1))
+        f = vra.frame_from_camera(view, pos, hi, lo, w, h)
+        assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, _oracle(ora, f, sphere64, kind),
+                            f"{kind} {w}x{h} from {pos}")
+    gpu.close()
+
+
+@pytest.mark.parametrize("kind", ["dense", "svo"])
+def test_row_bands_and_columns(vra, ora, teapot64, kind):
+    """Sub-rectangles (multi-GPU row bands): the band render equals the same rows of
+    the full frame, which needs the serial direction sums to be restarted exactly."""
+    hi, lo = _sizes(teapot64)
+    gpu = _upload(vra, teapot64, kind)
+    pos, view = vra.orbit_camera(3, 16, 1.0)
+    full = vra.frame_from_camera(view, pos, hi, lo, 200, 96)
+    want = _oracle(ora, full, teapot64, kind)
+    for (x0, y0, tw, th) in [(0, 24, 200, 24), (0, 72, 200, 24), (40, 13, 91, 50), (199, 95, 1, 1)]:
+        sub = full.copy()
+        sub.x0, sub.y0, sub.tile_w, sub.tile_h = x0, y0, tw, th
+        got = gpu.render(sub)
+        assert_planes_equal({k: v[0] for k, v in got.items()},
+                            {k: v[y0:y0 + th, x0:x0 + tw] for k, v in want.items()}, f"{kind} sub {x0},{y0},{tw},{th}")
+        assert_planes_equal({k: v[0] for k, v in got.items()}, _oracle(ora, sub, teapot64, kind), f"{kind} oracle sub")
+    gpu.close()
+
+
+def test_batch_crosses_launch_chunk(vra, ora, teapot64):
+    """More frames than one launch takes (32): frame-major output planes stay in order."""
+    hi, lo = _sizes(teapot64)
+    gpu = vra.GpuScene.upload_svo(teapot64.svo, teapot64.low)
+    frames = vra.orbit_frames(range(70), 70, hi, lo, 48, 40, radius=0.9)
+    got = gpu.render(frames, planes=("hit_index", "depth"))
+    for i in (0, 31, 32, 33, 63, 64, 69):
+        want = ora.render_frame(frames[i], low=teapot64.low, svo=teapot64.svo)
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"frame {i}")
+    gpu.close()
+
+
+def _manual_frame(vra, w, h, row0, xdiff, ydiff, origin, scale=1.0, naive=True):
+    f = vra._abi.FrameDesc()
+    for name, v in (("row0_hi", row0), ("xdiff_hi", xdiff), ("ydiff_hi", ydiff),
+                    ("row0_lo", row0), ("xdiff_lo", xdiff), ("ydiff_lo", ydiff),
+                    ("origin_hi", origin), ("origin_lo", origin)):
+        arr = getattr(f, name)
+        for c in range(3):
+            arr[c] = float(v[c])
+    for c in range(3):
+        f.scale_lo_to_hi[c] = scale
+    f.width, f.height, f.x0, f.y0, f.tile_w, f.tile_h = w, h, 0, 0, w, h
+    f.flags = 1 if naive else 0
+    return f
+
+
+@pytest.mark.parametrize("kind", ["dense", "svo"])
+def test_degenerate_rays(vra, ora, sphere64, kind):
+    """Direction components that are exactly zero (1/0 = inf, 0*inf = NaN inside the
+    DDA), rays parallel to a face outside the slab (NaN positions), rays that never
+    touch the volume, and an all-zero direction (normalize gives NaN)."""
+    gpu = _upload(vra, sphere64, kind)
+    cases = [
+        ((1, 0, 0), (0, 0, 0), (0, 0, 0), (-5, 32.5, 32.5)),        # +x through the centre
+        ((-1, 0, 0), (0, 0, 0), (0, 0, 0), (70, 32.5, 32.5)),       # -x
+        ((0, 0, 1), (0, 0, 0), (0, 0, 0), (32.5, 32.5, -3)),        # +z
+        ((1, 0, 0), (0, 0, 0), (0, 0, 0), (-5, -2.0, 32.5)),        # parallel, outside the slab: NaN
+        ((1, 0, 0), (0, 0.25, 0), (0, 0, 0.25), (-5, 30, 30)),      # fan with zero components in row 0 / col 0
+        ((0, 0, 0), (0, 0, 0), (0, 0, 0), (10, 10, 10)),            # zero direction
+        ((0, -1, 0), (0, 0, 0), (0, 0, 0), (0.0, 40, 0.0)),         # along an edge of the volume
+        ((1, 1, 1), (0, 0, 0), (0, 0, 0), (-1, -1, -1)),            # exact diagonal through cell corners
+    ]
+    for row0, xd, yd, org in cases:
+        f = _manual_frame(vra, 16, 8, row0, xd, yd, org)
+        assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, _oracle(ora, f, sphere64, kind),
+                            f"{kind} row0={row0} origin={org}")
+    gpu.close()
+
+
+def test_random_noncubic_dense(vra, ora):
+    """Random sparse occupancy in a grid whose sides are not multiples of the 4^3
+    brick, low grid with different aspect: exercises brick edges and payload fetch."""
+    rng = np.random.default_rng(7)
+    sz, sy, sx = 37, 50, 41
+    vox = np.zeros((sz, sy, sx, 8), np.uint8)
+    mask = rng.random((sz, sy, sx)) < 0.004
+    vox[mask] = rng.integers(1, 256, size=(int(mask.sum()), 8), dtype=np.uint8)
+    low = np.zeros((9, 13, 11, 8), np.uint8)
+    lmask = rng.random((9, 13, 11)) < 0.05
+    low[lmask] = 255
+    scene = vra.HostScene.from_dense(vox, low, svo=False)
+    gpu = vra.GpuScene.upload_dense(scene.target, scene.low)
+    for k in range(4):
+        pos, view = vra.orbit_camera(k, 4, 0.8)
+        for naive in (False, True):
+            f = vra.frame_from_camera(view, pos, (sx, sy, sz), (11, 13, 9), 96, 64, naive=naive)
+            want = ora.render_frame(f, low=scene.low, target=scene.target)
+            assert_planes_equal({k2: v[0] for k2, v in gpu.render(f).items()}, want, f"noncubic view {k} naive={naive}")
+    gpu.close()
+
+
+def test_empty_scene_and_errors(vra, ora):
+    vox = np.zeros((8, 8, 8, 8), np.uint8)
+    scene = vra.HostScene.from_dense(vox, None, svo=True)
+    for gpu in (vra.GpuScene.upload_dense(scene.target), vra.GpuScene.upload_svo(scene.svo)):
+        pos, view = vra.orbit_camera(1, 8, 0.9)
+        f = vra.frame_from_camera(view, pos, (8, 8, 8), (8, 8, 8), 40, 24, naive=True)
+        got = gpu.render(f)
+        assert (got["hit_index"] == MISS).all() and (got["rgba8"] == 255).all() and np.isinf(got["depth"]).all()
+        # a beam frame needs the low grid (VOLLY_E_UNSUPPORTED)
+        fb = vra.frame_from_camera(view, pos, (8, 8, 8), (8, 8, 8), 40, 24)
+        with pytest.raises(vra.VollyError) as e:
+            gpu.render(fb)
+        assert e.value.code == -4
+        bad = f.copy()
+        bad.tile_w = 41
+        with pytest.raises(vra.VollyError) as e:
+            gpu.render(bad)
+        assert e.value.code == -1
+        gpu.close()
+
+
+def test_noise_scene_matches_host_hash(vra, ora):
+    """volume_gpu_generate_noise: voxels equal the documented hash on the host, the
+    render of the generated scene equals the oracle on a host rebuild of it."""
+    res, seed, thr = 64, 3, 1 << 25
+    gpu = vra.GpuScene.noise(res, seed, thr)
+    dev = gpu.read_voxels(0, res ** 3).reshape(res, res, res, 8)
+    z, y, x = np.meshgrid(np.arange(res, dtype=np.uint32), np.arange(res, dtype=np.uint32),
+                          np.arange(res, dtype=np.uint32), indexing="ij")
+    with np.errstate(over="ignore"):
+        h = np.uint32(seed) * np.uint32(0x9E3779B1) + x * np.uint32(0x85EBCA77)
+        h ^= h >> np.uint32(15); h *= np.uint32(0x2C1B3C6D)
+        h += y * np.uint32(0xC2B2AE3D)
+        h ^= h >> np.uint32(13); h *= np.uint32(0x297A2D39)
+        h += z * np.uint32(0x27D4EB2F)
+        h ^= h >> np.uint32(16); h *= np.uint32(0x165667B1)
+        h ^= h >> np.uint32(15)
+    host = np.zeros((res, res, res, 8), np.uint8)
+    fill = h < thr
+    host[fill, 0:4] = 255
+    host[fill, 4] = ((h >> 8) & 0xFF)[fill]
+    host[fill, 5] = ((h >> 16) & 0xFF)[fill]
+    host[fill, 6] = ((h >> 24) & 0xFF)[fill]
+    assert np.array_equal(dev, host)
+    low = np.zeros((res // 4,) * 3 + (8,), np.uint8)
+    lfill = fill.reshape(res // 4, 4, res // 4, 4, res // 4, 4).any(axis=(1, 3, 5))
+    low[lfill, 0:4] = 255
+    scene = vra.HostScene.from_dense(host, low, svo=False)
+    pos, view = vra.orbit_camera(2, 9, 0.8)
+    f = vra.frame_from_camera(view, pos, (res,) * 3, (res // 4,) * 3, 128, 72)
+    assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()},
+                        ora.render_frame(f, low=scene.low, target=scene.target), "noise")
+    gpu.close()
+
+
+def test_device_entry_point_and_timing(vra, ora, teapot64):
+    """volume_gpu_render_device: device pointers (torch tensors), a non-default
+    stream, event timing."""
+    import torch
+    hi, lo = _sizes(teapot64)
+    gpu = vra.GpuScene.upload_svo(teapot64.svo, teapot64.low)
+    frames = vra.orbit_frames(range(3), 8, hi, lo, 96, 64, radius=0.9)
+    dev = torch.device("cuda:0")
+    planes = {p: torch.zeros((3, 64, 96), dtype=torch.float32 if p == "depth" else torch.int32, device=dev)
+              for p in ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")}
+    stream = torch.cuda.Stream(device=dev)
+    gpu.set_profiling(True)
+    with torch.cuda.stream(stream):
+        gpu.render_device(frames, {p: t.data_ptr() for p, t in planes.items()}, stream=stream.cuda_stream)
+    stream.synchronize()
+    ms, n = gpu.kernel_time()
+    assert n == 1 and ms > 0
+    for i, f in enumerate(frames):
+        want = ora.render_frame(f, low=teapot64.low, svo=teapot64.svo)
+        got = {p: t[i].cpu().numpy().view(np.float32 if p == "depth" else np.uint32) for p, t in planes.items()}
+        assert_planes_equal(got, want, f"device frame {i}")
+    gpu.close()
+
+
+def test_config2_dragon512_full_frame(vra, ora):
+    """BASELINE config 2: dragon.off at 512^3, octree target, 1920x1080, three
+    cameras; all five planes bit-exact against the oracle on the full frame."""
+    scene = vra.HostScene.from_mesh(os.path.join(ASSETS, "dragon.off"), 512, dense=False, svo=True)
+    hi, lo = (512,) * 3, (128,) * 3
+    gpu = vra.GpuScene.upload_svo(scene.svo, scene.low)
+    frames = vra.orbit_frames((0, 5, 11), 32, hi, lo, 1920, 1080, radius=1.0)
+    got = gpu.render(frames)
+    for i, f in enumerate(frames):
+        want = ora.render_frame(f, low=scene.low, svo=scene.svo, threads=16)
+        assert (want["hit_index"] != MISS).sum() > 50000
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"dragon512 view {i}")
+    gpu.close()

@@ -1,0 +1,432 @@
+// volly_gpu.hip -- C-ABI of the MI355X traversal path (include/volly_gpu.h).
+// Built for gfx950 only, with -ffp-contract=off (see volly_kernels.h).
+#include "volly_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? VOLLY_E_NOMEM : VOLLY_E_HIP,                  \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+// remembers the caller's current device and puts it back
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+constexpr int kFrameChunk = 32;     // frames per launch (bounds the checkpoint scratch)
+
+} // namespace
+
+struct volly_gpu_scene {
+    int device = 0;
+    bool is_svo = false, has_low = false;
+    vk::DenseDev target{}, low{};
+    vk::SvoDev svo{};
+    // owned device allocations
+    std::vector<void *> owned;
+    size_t bytes = 0;
+    // per-call scratch
+    volly_frame_desc *d_frames = nullptr;
+    float *d_ckpt = nullptr;
+    size_t ckpt_floats = 0;
+    void *d_planes = nullptr;       // staging of the synchronous entry point
+    size_t plane_bytes = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+namespace {
+
+int dev_alloc(volly_gpu_scene *s, void **p, size_t bytes)
+{
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 8));
+    s->owned.push_back(*p);
+    s->bytes += bytes;
+    return VOLLY_OK;
+}
+
+int check_dense(const volly_dense_desc *d, const char *what)
+{
+    if (!d || !d->voxels) return fail(VOLLY_E_ARG, std::string(what) + ": null grid");
+    if (d->sx < 1 || d->sy < 1 || d->sz < 1) return fail(VOLLY_E_ARG, std::string(what) + ": non-positive size");
+    if ((uint64_t)d->sx * (uint64_t)d->sy * (uint64_t)d->sz > (1ull << 31))
+        return fail(VOLLY_E_ARG, std::string(what) + ": more than 2^31 voxels (the reference indexes with int, volume.h:79-81)");
+    return VOLLY_OK;
+}
+
+// upload (or adopt) the 8-byte voxels of one grid and derive its occupancy bricks
+int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox, uint2 *dev_vox, vk::DenseDev *out)
+{
+    const size_t n = (size_t)sx * sy * sz;
+    uint2 *vox = dev_vox;
+    if (!vox) {
+        int rc = dev_alloc(s, (void **)&vox, n * 8);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(vox, host_vox, n * 8, hipMemcpyHostToDevice));
+    }
+    vk::DenseDev d{};
+    d.vox = vox;
+    d.sx = sx; d.sy = sy; d.sz = sz;
+    d.nbx = (sx + 3) / 4; d.nby = (sy + 3) / 4; d.nbz = (sz + 3) / 4;
+    d.fsx = (float)sx; d.fsy = (float)sy; d.fsz = (float)sz;
+    d.cap = 4u * (uint32_t)(sx + sy + sz) + 8u;
+    const size_t nb = (size_t)d.nbx * d.nby * d.nbz;
+    uint64_t *occ = nullptr;
+    int rc = dev_alloc(s, (void **)&occ, nb * 8);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vk::build_occupancy, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, vox, sx, sy, sz, d.nbx, d.nby,
+                       d.nbz, occ);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    d.occ = occ;
+    *out = d;
+    return VOLLY_OK;
+}
+
+void destroy(volly_gpu_scene *s)
+{
+    if (!s) return;
+    DeviceGuard g(s->device);
+    (void)hipDeviceSynchronize();
+    for (auto &e : s->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (void *p : s->owned) (void)hipFree(p);
+    if (s->d_frames) (void)hipFree(s->d_frames);
+    if (s->d_ckpt) (void)hipFree(s->d_ckpt);
+    if (s->d_planes) (void)hipFree(s->d_planes);
+    delete s;
+}
+
+int new_scene(int device, volly_gpu_scene **out)
+{
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(VOLLY_E_ARG, "no such device");
+    volly_gpu_scene *s = new (std::nothrow) volly_gpu_scene();
+    if (!s) return fail(VOLLY_E_NOMEM, "host allocation failed");
+    s->device = device;
+    *out = s;
+    return VOLLY_OK;
+}
+
+int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, int n_frames)
+{
+    if (!s || !frames || n_frames < 1) return fail(VOLLY_E_ARG, "render: null scene / frames or n_frames < 1");
+    const volly_frame_desc &f0 = frames[0];
+    for (int i = 0; i < n_frames; ++i) {
+        const volly_frame_desc &f = frames[i];
+        if (f.width < 1 || f.height < 1 || f.tile_w < 1 || f.tile_h < 1 || f.x0 < 0 || f.y0 < 0 ||
+            (int64_t)f.x0 + f.tile_w > f.width || (int64_t)f.y0 + f.tile_h > f.height)
+            return fail(VOLLY_E_ARG, "render: sub-rectangle outside the frame");
+        if (f.tile_w != f0.tile_w || f.tile_h != f0.tile_h)
+            return fail(VOLLY_E_ARG, "render: all frames of a call must share tile_w x tile_h");
+        if (f.flags & ~VOLLY_FRAME_NAIVE) return fail(VOLLY_E_ARG, "render: unknown frame flags");
+        if (!(f.flags & VOLLY_FRAME_NAIVE) && !s->has_low)
+            return fail(VOLLY_E_UNSUPPORTED, "render: beam frame on a scene uploaded without a low grid");
+    }
+    if ((uint64_t)f0.tile_w * (uint64_t)f0.tile_h * (uint64_t)n_frames > (1ull << 40))
+        return fail(VOLLY_E_ARG, "render: too many pixels in one call");
+    return VOLLY_OK;
+}
+
+int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size_t frame_offset, const volly_outputs *outs,
+                 hipStream_t stream)
+{
+    const int tw = frames[0].tile_w, th = frames[0].tile_h;
+    const int groups = (tw + vk::kTile - 1) / vk::kTile;
+    const size_t need = (size_t)n * groups * th * 6;
+    if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, sizeof(volly_frame_desc) * kFrameChunk));
+    if (need > s->ckpt_floats) {
+        if (s->d_ckpt) { HIP_TRY(hipFree(s->d_ckpt)); s->d_ckpt = nullptr; s->ckpt_floats = 0; }
+        HIP_TRY(hipMalloc((void **)&s->d_ckpt, need * sizeof(float)));
+        s->ckpt_floats = need;
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_frames, frames, sizeof(volly_frame_desc) * (size_t)n, hipMemcpyHostToDevice, stream));
+
+    hipLaunchKernelGGL(vk::direction_checkpoints, dim3((unsigned)((th + 63) / 64), (unsigned)n), dim3(64), 0, stream,
+                       s->d_frames, n, s->d_ckpt);
+    HIP_TRY(hipGetLastError());
+
+    const size_t px = (size_t)tw * th * frame_offset;
+    vk::OutDev o{};
+    o.rgba8 = outs->rgba8 ? outs->rgba8 + px : nullptr;
+    o.hit_index = outs->hit_index ? outs->hit_index + px : nullptr;
+    o.steps_lo = outs->steps_lo ? outs->steps_lo + px : nullptr;
+    o.steps_hi = outs->steps_hi ? outs->steps_hi + px : nullptr;
+    o.depth = outs->depth ? outs->depth + px : nullptr;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->profiling) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, stream));
+    }
+    dim3 grid((unsigned)((tw + vk::kBlockW - 1) / vk::kBlockW), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
+    if (s->is_svo)
+        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
+                           s->d_ckpt, o);
+    else
+        hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
+                           s->d_ckpt, o);
+    HIP_TRY(hipGetLastError());
+    if (s->profiling) {
+        HIP_TRY(hipEventRecord(e1, stream));
+        s->events.emplace_back(e0, e1);
+    }
+    return VOLLY_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int volly_gpu_abi_version(void) { return 1; }
+
+const char *volly_gpu_last_error(void) { return g_err.c_str(); }
+
+int volume_gpu_upload(int device, const volly_dense_desc *target, const volly_dense_desc *low, volly_gpu_scene **out)
+{
+    if (!out) return fail(VOLLY_E_ARG, "volume_gpu_upload: out is null");
+    *out = nullptr;
+    int rc = check_dense(target, "volume_gpu_upload target");
+    if (rc) return rc;
+    if (low && (rc = check_dense(low, "volume_gpu_upload low"))) return rc;
+    volly_gpu_scene *s = nullptr;
+    if ((rc = new_scene(device, &s))) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) { destroy(s); return fail(VOLLY_E_HIP, "hipSetDevice failed"); }
+    rc = make_dense(s, target->sx, target->sy, target->sz, target->voxels, nullptr, &s->target);
+    if (!rc && low) {
+        rc = make_dense(s, low->sx, low->sy, low->sz, low->voxels, nullptr, &s->low);
+        s->has_low = true;
+    }
+    if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
+    *out = s;
+    return VOLLY_OK;
+}
+
+int svo_gpu_upload(int device, const volly_svo_desc *svo, const volly_dense_desc *low, volly_gpu_scene **out)
+{
+    if (!out) return fail(VOLLY_E_ARG, "svo_gpu_upload: out is null");
+    *out = nullptr;
+    if (!svo || !svo->nodes || svo->n_nodes < 1 || (svo->n_leaves && !svo->leaves))
+        return fail(VOLLY_E_ARG, "svo_gpu_upload: null octree");
+    if (svo->depth < 1 || svo->depth > 13 || svo->res < 1 || svo->res > (1 << svo->depth))
+        return fail(VOLLY_E_ARG, "svo_gpu_upload: need 1 <= depth <= 13 and 1 <= res <= 2^depth");
+    // The kernel trusts the tree: check that every child reference stays inside the
+    // arrays, points forward (breadth-first order) and that leaves sit exactly at
+    // level 1, so a walk from the root ends after at most `depth` nodes.
+    {
+        const volly_svo_node *nd = svo->nodes;
+        std::vector<int8_t> level(svo->n_nodes, (int8_t)-1);
+        level[0] = (int8_t)svo->depth;
+        for (uint32_t i = 0; i < svo->n_nodes; ++i) {
+            const uint32_t cnt = (uint32_t)__builtin_popcount(nd[i].valid_mask);
+            if (level[i] < 1) return fail(VOLLY_E_ARG, "svo_gpu_upload: unreachable node or tree deeper than depth");
+            const bool leaf_level = level[i] == 1;
+            if (nd[i].leaf_mask != (leaf_level ? nd[i].valid_mask : 0))
+                return fail(VOLLY_E_ARG, "svo_gpu_upload: leaf_mask must equal valid_mask at level 1 and be 0 above");
+            const uint64_t end = (uint64_t)nd[i].child_offset + cnt;
+            if (leaf_level) {
+                if (end > svo->n_leaves) return fail(VOLLY_E_ARG, "svo_gpu_upload: leaf offset out of range");
+            } else if (cnt) {
+                if (end > svo->n_nodes || nd[i].child_offset <= i)
+                    return fail(VOLLY_E_ARG, "svo_gpu_upload: child offset out of range");
+                for (uint32_t c = 0; c < cnt; ++c) level[nd[i].child_offset + c] = (int8_t)(level[i] - 1);
+            }
+        }
+    }
+    int rc;
+    if (low && (rc = check_dense(low, "svo_gpu_upload low"))) return rc;
+    volly_gpu_scene *s = nullptr;
+    if ((rc = new_scene(device, &s))) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) { destroy(s); return fail(VOLLY_E_HIP, "hipSetDevice failed"); }
+    s->is_svo = true;
+    uint2 *nodes = nullptr, *leaves = nullptr;
+    rc = dev_alloc(s, (void **)&nodes, (size_t)svo->n_nodes * 8);
+    if (!rc) rc = dev_alloc(s, (void **)&leaves, (size_t)svo->n_leaves * 8);
+    if (!rc && hipMemcpy(nodes, svo->nodes, (size_t)svo->n_nodes * 8, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(VOLLY_E_HIP, "svo_gpu_upload: node copy failed");
+    if (!rc && svo->n_leaves && hipMemcpy(leaves, svo->leaves, (size_t)svo->n_leaves * 8, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(VOLLY_E_HIP, "svo_gpu_upload: leaf copy failed");
+    if (!rc) {
+        s->svo.nodes = nodes; s->svo.leaves = leaves;
+        s->svo.n_nodes = svo->n_nodes;
+        s->svo.depth = svo->depth; s->svo.res = svo->res; s->svo.fres = (float)svo->res;
+        s->svo.cap = 4u * (uint32_t)(3 * svo->res) + 8u;
+        s->target.sx = s->target.sy = s->target.sz = svo->res;
+    }
+    if (!rc && low) {
+        rc = make_dense(s, low->sx, low->sy, low->sz, low->voxels, nullptr, &s->low);
+        s->has_low = true;
+    }
+    if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
+    *out = s;
+    return VOLLY_OK;
+}
+
+int volume_gpu_generate_noise(int device, int32_t res, uint32_t seed, uint32_t threshold, volly_gpu_scene **out)
+{
+    if (!out) return fail(VOLLY_E_ARG, "volume_gpu_generate_noise: out is null");
+    *out = nullptr;
+    if (res < 4 || res > 1024 || (res % 4) != 0) return fail(VOLLY_E_ARG, "volume_gpu_generate_noise: res must be a multiple of 4 in [4,1024]");
+    volly_gpu_scene *s = nullptr;
+    int rc = new_scene(device, &s);
+    if (rc) return rc;
+    DeviceGuard g(device);
+    if (!g.ok) { destroy(s); return fail(VOLLY_E_HIP, "hipSetDevice failed"); }
+    const size_t n = (size_t)res * res * res;
+    uint2 *vox = nullptr, *vox_lo = nullptr;
+    rc = dev_alloc(s, (void **)&vox, n * 8);
+    if (!rc) {
+        hipLaunchKernelGGL(vk::generate_noise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, vox, res, seed, threshold);
+        if (hipGetLastError() != hipSuccess) rc = fail(VOLLY_E_HIP, "generate_noise launch failed");
+    }
+    if (!rc) rc = make_dense(s, res, res, res, nullptr, vox, &s->target);
+    const int lr = res / 4;
+    const size_t nl = (size_t)lr * lr * lr;
+    if (!rc) rc = dev_alloc(s, (void **)&vox_lo, nl * 8);
+    if (!rc) {
+        hipLaunchKernelGGL(vk::reduce_low, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, 0, s->target.occ, lr, lr, lr, vox_lo);
+        if (hipGetLastError() != hipSuccess) rc = fail(VOLLY_E_HIP, "reduce_low launch failed");
+    }
+    if (!rc) rc = make_dense(s, lr, lr, lr, nullptr, vox_lo, &s->low);
+    if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
+    s->has_low = true;
+    *out = s;
+    return VOLLY_OK;
+}
+
+int volume_gpu_render_device(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames, const volly_outputs *outs,
+                             void *hip_stream)
+{
+    int rc = validate_frames(scene, frames, n_frames);
+    if (rc) return rc;
+    if (!outs) return fail(VOLLY_E_ARG, "render: outs is null");
+    DeviceGuard g(scene->device);
+    if (!g.ok) return fail(VOLLY_E_HIP, "hipSetDevice failed");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    for (int first = 0; first < n_frames; first += kFrameChunk) {
+        const int n = std::min(kFrameChunk, n_frames - first);
+        if ((rc = render_chunk(scene, frames + first, n, (size_t)first, outs, stream))) return rc;
+    }
+    return VOLLY_OK;
+}
+
+int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames, const volly_outputs *outs)
+{
+    int rc = validate_frames(scene, frames, n_frames);
+    if (rc) return rc;
+    if (!outs) return fail(VOLLY_E_ARG, "render: outs is null");
+    DeviceGuard g(scene->device);
+    if (!g.ok) return fail(VOLLY_E_HIP, "hipSetDevice failed");
+    const size_t px = (size_t)frames[0].tile_w * frames[0].tile_h * (size_t)n_frames;
+    void *host[5] = {outs->rgba8, outs->hit_index, outs->steps_lo, outs->steps_hi, outs->depth};
+    size_t wanted = 0;
+    for (void *h : host) wanted += h ? 1 : 0;
+    if (wanted * px * 4 > scene->plane_bytes) {
+        if (scene->d_planes) { HIP_TRY(hipFree(scene->d_planes)); scene->d_planes = nullptr; scene->plane_bytes = 0; }
+        HIP_TRY(hipMalloc(&scene->d_planes, wanted * px * 4));
+        scene->plane_bytes = wanted * px * 4;
+    }
+    uint32_t *dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t k = 0;
+    for (int i = 0; i < 5; ++i)
+        if (host[i]) dev[i] = (uint32_t *)scene->d_planes + (k++) * px;
+    volly_outputs d{dev[0], dev[1], dev[2], dev[3], (float *)dev[4]};
+    if ((rc = volume_gpu_render_device(scene, frames, n_frames, &d, nullptr))) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    for (int i = 0; i < 5; ++i)
+        if (host[i]) HIP_TRY(hipMemcpy(host[i], dev[i], px * 4, hipMemcpyDeviceToHost));
+    return VOLLY_OK;
+}
+
+int volly_gpu_set_profiling(volly_gpu_scene *scene, int enabled)
+{
+    if (!scene) return fail(VOLLY_E_ARG, "null scene");
+    scene->profiling = enabled != 0;
+    return VOLLY_OK;
+}
+
+int volly_gpu_kernel_time(volly_gpu_scene *scene, double *ms_total, int *launches)
+{
+    if (!scene || !ms_total || !launches) return fail(VOLLY_E_ARG, "null argument");
+    DeviceGuard g(scene->device);
+    double total = 0.0;
+    int n = 0;
+    for (auto &e : scene->events) {
+        HIP_TRY(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        total += ms;
+        ++n;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    scene->events.clear();
+    *ms_total = total;
+    *launches = n;
+    return VOLLY_OK;
+}
+
+int volly_gpu_read_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count, void *out)
+{
+    if (!scene || !out) return fail(VOLLY_E_ARG, "null argument");
+    if (scene->is_svo) return fail(VOLLY_E_UNSUPPORTED, "scene has no dense target");
+    const uint64_t n = (uint64_t)scene->target.sx * scene->target.sy * scene->target.sz;
+    if (first > n || count > n - first) return fail(VOLLY_E_ARG, "range outside the grid");
+    DeviceGuard g(scene->device);
+    HIP_TRY(hipMemcpy(out, scene->target.vox + first, count * 8, hipMemcpyDeviceToHost));
+    return VOLLY_OK;
+}
+
+int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
+{
+    if (!s) return -1;
+    switch (what) {
+    case 0: return s->target.sx;
+    case 1: return s->target.sy;
+    case 2: return s->target.sz;
+    case 3: return s->is_svo;
+    case 4: return s->has_low;
+    case 5: return s->has_low ? s->low.sx : 0;
+    case 6: return s->device;
+    case 7: return (int64_t)(s->bytes >> 20);
+    default: return -1;
+    }
+}
+
+void volly_gpu_free(volly_gpu_scene *scene) { destroy(scene); }
+
+} // extern "C"

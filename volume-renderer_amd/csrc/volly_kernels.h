@@ -1,0 +1,402 @@
+// volly_kernels.h -- gfx950 device code of the primary-ray traversal path.
+//
+// What the kernels compute is fixed by the reference (file:line cited at each
+// function); how they compute it is MI355X-first:
+//   * one ray per lane, one 64-lane wavefront per 8x8 pixel tile, four tiles side
+//     by side per 256-thread workgroup (a 32x8 pixel block, so every output row
+//     of the block is one 128-byte store per plane);
+//   * the dense grids are traversed through a derived 1-bit occupancy structure
+//     (4x4x4-voxel bricks, one 64-bit word each) kept beside the reference's 8-byte
+//     voxels; the 8-byte Voxel (voxel.h:13-16) is fetched once, at the hit.  A
+//     lane keeps the current brick word in registers, so most DDA steps touch
+//     no memory at all;
+//   * every float operation is the reference's, in the reference's order, unfused
+//     (the file is compiled with -ffp-contract=off): hit index, step counts, end
+//     point and depth are bit-identical to the CPU restatement;
+//   * per-pixel ray directions are the reference's serial "+= xdiff" sums
+//     (main.cpp:282-286): a small pre-pass stores the running sum every 8 pixels,
+//     each lane finishes with at most 7 adds.
+#ifndef VOLLY_KERNELS_H
+#define VOLLY_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "volly_gpu.h"
+
+namespace vk {
+
+constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
+constexpr int kBlockW = 32;         // workgroup covers 32 x 8 pixels
+constexpr int kBlockH = 8;
+constexpr int kThreads = 256;
+constexpr int kTopNodes = 585;      // octree levels 0..3 (1 + 8 + 64 + 512 nodes) staged in LDS
+
+struct DenseDev {
+    const uint64_t *occ;            // one word per 4x4x4 brick, bit = x&3 | (y&3)<<2 | (z&3)<<4
+    const uint2 *vox;               // the reference's 8-byte voxels, x + sx*(y + sy*z)
+    int sx, sy, sz;
+    int nbx, nby, nbz;              // bricks per axis
+    float fsx, fsy, fsz;
+    uint32_t cap;                   // iteration cap 4*(sx+sy+sz)+8 (the reference has none, main.cpp:121)
+};
+
+struct SvoDev {
+    const uint2 *nodes;             // .x = child_offset, .y = valid_mask | leaf_mask<<8
+    const uint2 *leaves;
+    uint32_t n_nodes;
+    int depth, res;
+    float fres;
+    uint32_t cap;
+};
+
+struct OutDev {
+    uint32_t *rgba8, *hit_index, *steps_lo, *steps_hi;
+    float *depth;
+};
+
+struct Ray {
+    float dx, dy, dz;               // direction
+    float ix, iy, iz;               // 1/direction
+    float hx, hy, hz;               // heaviside: 0 for a negative component, else 1
+    float ex, ey, ez;               // sign * eps
+};
+
+// main.cpp:96-102
+__device__ __forceinline__ Ray make_ray(float dx, float dy, float dz)
+{
+    const float eps = 0.00030f;
+    Ray r;
+    r.dx = dx; r.dy = dy; r.dz = dz;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    // heaviside = round((sign+1)/2): 0 for sign -1, 1 for sign +1 and, rounding half away from zero, for sign 0
+    r.hx = (dx < 0.0f) ? 0.0f : 1.0f;
+    r.hy = (dy < 0.0f) ? 0.0f : 1.0f;
+    r.hz = (dz < 0.0f) ? 0.0f : 1.0f;
+    float sx = (float)((0.0f < dx) - (dx < 0.0f));
+    float sy = (float)((0.0f < dy) - (dy < 0.0f));
+    float sz = (float)((0.0f < dz) - (dz < 0.0f));
+    r.ex = sx * eps; r.ey = sy * eps; r.ez = sz * eps;
+    return r;
+}
+
+// main.cpp:105-108
+__device__ __forceinline__ void enter_volume(const Ray &r, float ox, float oy, float oz, float vx, float vy, float vz,
+                                             float &cx, float &cy, float &cz)
+{
+    float ndx = (-(vx * (r.hx - 1.0f) + ox)) * r.ix;
+    float ndy = (-(vy * (r.hy - 1.0f) + oy)) * r.iy;
+    float ndz = (-(vz * (r.hz - 1.0f) + oz)) * r.iz;
+    float t0 = fmaxf(fmaxf(fmaxf(ndx, ndy), ndz), 0.0f);
+    cx = t0 * r.dx + ox;
+    cy = t0 * r.dy + oy;
+    cz = t0 * r.dz + oz;
+}
+
+// main.cpp:149-153, unit cells
+__device__ __forceinline__ void advance_unit(const Ray &r, float px, float py, float pz, float &cx, float &cy, float &cz)
+{
+    float ndx = ((floorf(px) + r.hx) - cx) * r.ix;
+    float ndy = ((floorf(py) + r.hy) - cy) * r.iy;
+    float ndz = ((floorf(pz) + r.hz) - cz) * r.iz;
+    float m = fminf(fminf(ndx, ndy), ndz);
+    cx = m * r.dx + cx;
+    cy = m * r.dy + cy;
+    cz = m * r.dz + cz;
+}
+
+// the same step across an empty octree cell of 2^k voxels (s = 2^k, is = 2^-k: both scalings are exact)
+__device__ __forceinline__ void advance_cell(const Ray &r, float s, float is, float px, float py, float pz,
+                                             float &cx, float &cy, float &cz)
+{
+    float ndx = ((floorf(px * is) * s + r.hx * s) - cx) * r.ix;
+    float ndy = ((floorf(py * is) * s + r.hy * s) - cy) * r.iy;
+    float ndz = ((floorf(pz * is) * s + r.hz * s) - cz) * r.iz;
+    float m = fminf(fminf(ndx, ndy), ndz);
+    cx = m * r.dx + cx;
+    cy = m * r.dy + cy;
+    cz = m * r.dz + cz;
+}
+
+struct Hit {
+    float cx, cy, cz;               // ptEnd (cur at the hit or at the exit)
+    uint32_t steps;
+    uint32_t index;                 // dense linear index of the hit voxel, VOLLY_MISS_INDEX on a miss
+    uint32_t payload;               // dense: = index; octree: index into leaves[]
+};
+
+// raycast_naiive_vec4<false> (main.cpp:88-161) on the occupancy bricks of a dense grid.
+// The reference tests roundPos = (int)curPlusEpsilon against [0,size): for the
+// x86 conversion (truncation; NaN / out of range -> INT_MIN) that is exactly
+// -1 < curPlusEpsilon < size, NaN failing, which is what is tested here.
+__device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    int last_brick = -1;
+    uint64_t bits = 0;
+    for (;;) {
+        float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
+        bool inside = (px > -1.0f) & (px < g.fsx) & (py > -1.0f) & (py < g.fsy) & (pz > -1.0f) & (pz < g.fsz);
+        if (!inside) break;
+        if (h.steps >= g.cap) break;
+        int x = (int)px, y = (int)py, z = (int)pz;       // truncation toward zero, like glm::ivec4(vec4)
+        ++h.steps;
+        int brick = (x >> 2) + g.nbx * ((y >> 2) + g.nby * (z >> 2));
+        if (brick != last_brick) {
+            bits = g.occ[brick];
+            last_brick = brick;
+        }
+        uint32_t bit = (uint32_t)(x & 3) | ((uint32_t)(y & 3) << 2) | ((uint32_t)(z & 3) << 4);
+        if ((bits >> bit) & 1ull) {
+            h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
+            h.payload = h.index;
+            break;
+        }
+        advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
+    }
+    return h;
+}
+
+// Octree traversal (no reference implementation: svo.cpp:14-19 is empty).  Each
+// iteration locates the sample cell by walking down from the root -- top levels
+// from LDS, the rest from L2/HBM -- and either hits a leaf voxel or steps across
+// the largest empty octree cell around the sample point.
+__device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, t.fres, t.fres, t.fres, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    for (;;) {
+        float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
+        bool inside = (px > -1.0f) & (px < t.fres) & (py > -1.0f) & (py < t.fres) & (pz > -1.0f) & (pz < t.fres);
+        if (!inside) break;
+        if (h.steps >= t.cap) break;
+        int x = (int)px, y = (int)py, z = (int)pz;
+        ++h.steps;
+
+        uint2 n = top[0];
+        int sh = t.depth - 1;
+        bool hit = false;
+        for (;;) {
+            uint32_t oct = ((uint32_t)(x >> sh) & 1u) | (((uint32_t)(y >> sh) & 1u) << 1) | (((uint32_t)(z >> sh) & 1u) << 2);
+            uint32_t valid = n.y & 0xFFu;
+            uint32_t bit = 1u << oct;
+            if (!(valid & bit)) break;                    // empty cell of 2^sh voxels
+            uint32_t child = n.x + (uint32_t)__popc(valid & (bit - 1u));
+            if ((n.y >> 8) & bit) {                       // leaf voxel
+                h.payload = child;
+                hit = true;
+                break;
+            }
+            n = (child < (uint32_t)kTopNodes) ? top[child] : t.nodes[child];
+            --sh;
+        }
+        if (hit) {
+            h.index = (uint32_t)x + (uint32_t)t.res * ((uint32_t)y + (uint32_t)t.res * (uint32_t)z);
+            break;
+        }
+        float s = __uint_as_float((uint32_t)(127 + sh) << 23);
+        float is = __uint_as_float((uint32_t)(127 - sh) << 23);
+        advance_cell(r, s, is, px, py, pz, h.cx, h.cy, h.cz);
+    }
+    return h;
+}
+
+// glm::normalize(vec4(x,y,z,0)): v * (1/sqrt((xx+yy)+(zz+ww)))
+__device__ __forceinline__ void normalize_w0(float &x, float &y, float &z)
+{
+    float d = (x * x + y * y) + (z * z + 0.0f);
+    float inv = 1.0f / sqrtf(d);
+    x = x * inv; y = y * inv; z = z * inv;
+}
+
+// main.cpp:264-269
+__device__ __forceinline__ uint32_t shade(uint2 vox)
+{
+    float inv = 1.0f / sqrtf((1.0f + 1.0f) + (1.0f + 0.0f));
+    float sun = 1.0f * inv;
+    float sun_w = 0.0f * inv;
+    float nx = (float)(vox.y & 0xFFu) / 255.0f;
+    float ny = (float)((vox.y >> 8) & 0xFFu) / 255.0f;
+    float nz = (float)((vox.y >> 16) & 0xFFu) / 255.0f;
+    float nw = (float)(vox.y >> 24) / 255.0f;
+    float d = (sun * nx + sun * ny) + (sun * nz + sun_w * nw);
+    float l = d / 2.0f + 0.5f;
+    l = fminf(fmaxf(l, 0.0f), 1.0f);
+    uint32_t cr = (uint32_t)((float)(vox.x & 0xFFu) * l) & 0xFFu;
+    uint32_t cg = (uint32_t)((float)((vox.x >> 8) & 0xFFu) * l) & 0xFFu;
+    uint32_t cb = (uint32_t)((float)((vox.x >> 16) & 0xFFu) * l) & 0xFFu;
+    return 255u | (cr << 8) | (cg << 16) | (cb << 24);
+}
+
+// ---- pre-pass: serial ray-direction sums (main.cpp:254-255,282-286) -----------
+// One thread per (frame, row of the sub-rectangle).  Walks the row's running
+// sums and stores them every kTile pixels, for both the target and the low grid.
+// ckpt layout: [frame][column group][row][6 floats] (hi xyz, lo xyz).
+__global__ void __launch_bounds__(64)
+direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames, float *__restrict__ ckpt)
+{
+    const int f = blockIdx.y;
+    if (f >= n_frames) return;
+    const volly_frame_desc fd = frames[f];                // private copy: the loops below must not re-read it
+    const int yrel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (yrel >= fd.tile_h) return;
+    const int y = fd.y0 + yrel;
+    float hx = fd.row0_hi[0], hy = fd.row0_hi[1], hz = fd.row0_hi[2];
+    float lx = fd.row0_lo[0], ly = fd.row0_lo[1], lz = fd.row0_lo[2];
+    const float yhx = fd.ydiff_hi[0], yhy = fd.ydiff_hi[1], yhz = fd.ydiff_hi[2];
+    const float ylx = fd.ydiff_lo[0], yly = fd.ydiff_lo[1], ylz = fd.ydiff_lo[2];
+    for (int i = 0; i < y; ++i) {                         // main.cpp:285-286
+        hx = hx + yhx; hy = hy + yhy; hz = hz + yhz;
+        lx = lx + ylx; ly = ly + yly; lz = lz + ylz;
+    }
+    const float xhx = fd.xdiff_hi[0], xhy = fd.xdiff_hi[1], xhz = fd.xdiff_hi[2];
+    const float xlx = fd.xdiff_lo[0], xly = fd.xdiff_lo[1], xlz = fd.xdiff_lo[2];
+    const int groups = (fd.tile_w + kTile - 1) / kTile;
+    const size_t frame_base = (size_t)f * (size_t)groups * (size_t)fd.tile_h;
+    for (int x = 0; x < fd.x0; ++x) {                     // main.cpp:282-283, columns left of the sub-rectangle
+        hx = hx + xhx; hy = hy + xhy; hz = hz + xhz;
+        lx = lx + xlx; ly = ly + xly; lz = lz + xlz;
+    }
+    for (int g = 0; g < groups; ++g) {
+        float *o = ckpt + (frame_base + (size_t)g * (size_t)fd.tile_h + (size_t)yrel) * 6;
+        o[0] = hx; o[1] = hy; o[2] = hz; o[3] = lx; o[4] = ly; o[5] = lz;
+        #pragma unroll
+        for (int i = 0; i < kTile; ++i) {
+            hx = hx + xhx; hy = hy + xhy; hz = hz + xhz;
+            lx = lx + xlx; ly = ly + xly; lz = lz + xlz;
+        }
+    }
+}
+
+// ---- the frame kernel: main.cpp:256-272 for every pixel of the sub-rectangle --
+template <bool SVO>
+__global__ void __launch_bounds__(kThreads)
+render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
+              const float *__restrict__ ckpt, OutDev out)
+{
+    __shared__ uint2 top[SVO ? kTopNodes : 1];
+    __shared__ uint32_t stage[5][kBlockH][kBlockW];
+
+    if (SVO) {
+        const uint32_t n = svo.n_nodes < (uint32_t)kTopNodes ? svo.n_nodes : (uint32_t)kTopNodes;
+        for (uint32_t i = threadIdx.x; i < n; i += kThreads) top[i] = svo.nodes[i];
+        __syncthreads();
+    }
+
+    const int f = blockIdx.z;
+    const volly_frame_desc fd = frames[f];                // uniform: lives in SGPRs
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int px_in_block = wave * kTile + (lane & 7);
+    const int py_in_block = lane >> 3;
+    const int xrel = blockIdx.x * kBlockW + px_in_block;
+    const int yrel = blockIdx.y * kBlockH + py_in_block;
+    const bool active = (xrel < fd.tile_w) & (yrel < fd.tile_h);
+
+    uint32_t o_rgba = 255u, o_hit = VOLLY_MISS_INDEX, o_slo = 0, o_shi = 0;
+    float o_depth = __uint_as_float(0x7F800000u);
+
+    if (active) {
+        const int groups = (fd.tile_w + kTile - 1) / kTile;
+        const float *c = ckpt + (((size_t)f * (size_t)groups + (size_t)(xrel / kTile)) * (size_t)fd.tile_h + (size_t)yrel) * 6;
+        float hx = c[0], hy = c[1], hz = c[2], lx = c[3], ly = c[4], lz = c[5];
+        const int extra = xrel % kTile;
+        for (int i = 0; i < extra; ++i) {                 // main.cpp:282-283
+            hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];
+            lx = lx + fd.xdiff_lo[0]; ly = ly + fd.xdiff_lo[1]; lz = lz + fd.xdiff_lo[2];
+        }
+        normalize_w0(hx, hy, hz);                         // main.cpp:260
+        const Ray ray_hi = make_ray(hx, hy, hz);
+
+        float sx, sy, sz;                                 // start of the target-grid pass
+        if (fd.flags & VOLLY_FRAME_NAIVE) {               // main.cpp:261
+            sx = fd.origin_hi[0]; sy = fd.origin_hi[1]; sz = fd.origin_hi[2];
+        } else {                                          // raycast_beamOpt, main.cpp:163-166
+            normalize_w0(lx, ly, lz);
+            const Ray ray_lo = make_ray(lx, ly, lz);
+            Hit lo = trace_dense(low, ray_lo, fd.origin_lo[0], fd.origin_lo[1], fd.origin_lo[2]);
+            o_slo = lo.steps;
+            sx = fd.scale_lo_to_hi[0] * lo.cx; sy = fd.scale_lo_to_hi[1] * lo.cy; sz = fd.scale_lo_to_hi[2] * lo.cz;
+        }
+
+        Hit hi = SVO ? trace_svo(svo, top, ray_hi, sx, sy, sz) : trace_dense(target, ray_hi, sx, sy, sz);
+        o_shi = hi.steps;
+        o_hit = hi.index;
+        if (hi.index != VOLLY_MISS_INDEX) {
+            uint2 vox = SVO ? svo.leaves[hi.payload] : target.vox[hi.payload];
+            o_rgba = shade(vox);
+            float ddx = hi.cx - fd.origin_hi[0], ddy = hi.cy - fd.origin_hi[1], ddz = hi.cz - fd.origin_hi[2];
+            o_depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
+        }
+    }
+
+    // framebuffer writeback: through LDS so that every store instruction writes
+    // whole 128-byte row segments (main.cpp:269-271 writes data_stream[x + y*W])
+    stage[0][py_in_block][px_in_block] = o_rgba;
+    stage[1][py_in_block][px_in_block] = o_hit;
+    stage[2][py_in_block][px_in_block] = o_slo;
+    stage[3][py_in_block][px_in_block] = o_shi;
+    stage[4][py_in_block][px_in_block] = __float_as_uint(o_depth);
+    __syncthreads();
+    const int wx = threadIdx.x & 31, wy = threadIdx.x >> 5;
+    const int oxr = blockIdx.x * kBlockW + wx, oyr = blockIdx.y * kBlockH + wy;
+    if (oxr < fd.tile_w && oyr < fd.tile_h) {
+        const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)oyr * (size_t)fd.tile_w + (size_t)oxr;
+        if (out.rgba8) out.rgba8[p] = stage[0][wy][wx];
+        if (out.hit_index) out.hit_index[p] = stage[1][wy][wx];
+        if (out.steps_lo) out.steps_lo[p] = stage[2][wy][wx];
+        if (out.steps_hi) out.steps_hi[p] = stage[3][wy][wx];
+        if (out.depth) out.depth[p] = __uint_as_float(stage[4][wy][wx]);
+    }
+}
+
+// ---- scene preparation --------------------------------------------------------
+
+// occupancy bricks from the reference's voxels: bit set iff rgba.a > 0 (main.cpp:140)
+__global__ void __launch_bounds__(256) build_occupancy(const uint2 *vox, int sx, int sy, int sz, int nbx, int nby, int nbz,
+                                                       uint64_t *occ)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nb = (size_t)nbx * nby * nbz;
+    if (b >= nb) return;
+    const int bx = (int)(b % (size_t)nbx), by = (int)((b / (size_t)nbx) % (size_t)nby), bz = (int)(b / ((size_t)nbx * nby));
+    uint64_t bits = 0;
+    for (int k = 0; k < 64; ++k) {
+        const int x = bx * 4 + (k & 3), y = by * 4 + ((k >> 2) & 3), z = bz * 4 + (k >> 4);
+        if (x < sx && y < sy && z < sz) {
+            const uint2 v = vox[(size_t)x + (size_t)sx * ((size_t)y + (size_t)sy * (size_t)z)];
+            if ((v.x >> 24) != 0) bits |= 1ull << k;
+        }
+    }
+    occ[b] = bits;
+}
+
+// synthetic noise voxels (volume_gpu_generate_noise)
+__global__ void __launch_bounds__(256) generate_noise(uint2 *vox, int res, uint32_t seed, uint32_t threshold)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)res * res * res;
+    if (i >= n) return;
+    const uint32_t x = (uint32_t)(i % (size_t)res), y = (uint32_t)((i / (size_t)res) % (size_t)res), z = (uint32_t)(i / ((size_t)res * res));
+    const uint32_t h = volly_noise_hash(x, y, z, seed);
+    uint2 v = make_uint2(0u, 0u);
+    if (h < threshold) { v.x = 0xFFFFFFFFu; v.y = (h >> 8) & 0x00FFFFFFu; }
+    vox[i] = v;
+}
+
+// low grid of a synthetic scene: cell filled (white, zero normal) iff any of its 4^3 voxels is
+__global__ void __launch_bounds__(256) reduce_low(const uint64_t *occ_hi, int nbx, int nby, int nbz, uint2 *vox_lo)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nb = (size_t)nbx * nby * nbz;
+    if (b >= nb) return;
+    vox_lo[b] = occ_hi[b] ? make_uint2(0xFFFFFFFFu, 0u) : make_uint2(0u, 0u);
+}
+
+} // namespace vk
+#endif

@@ -1,0 +1,143 @@
+"""ctypes binding of lib/libvolly_gpu.so (include/volly_gpu.h): the HIP path.
+
+There is no CPU fallback: if the library is missing the import fails, and every
+entry point raises VollyError on a non-zero return code."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (LIB_DIR, DenseDesc, SvoDesc, FrameDesc, Outputs, PLANES, VOLLY_OK)
+
+_path = os.path.join(LIB_DIR, "libvolly_gpu.so")
+if not os.path.exists(_path):
+    raise ImportError(f"{_path} is missing: the HIP extension must be built (make gpu / __graft_entry__.build()); "
+                      "there is no CPU fallback")
+lib = C.CDLL(_path)
+
+_vp = C.c_void_p
+_sig = {
+    "volume_gpu_upload": (C.c_int, [C.c_int, C.POINTER(DenseDesc), C.POINTER(DenseDesc), C.POINTER(_vp)]),
+    "svo_gpu_upload": (C.c_int, [C.c_int, C.POINTER(SvoDesc), C.POINTER(DenseDesc), C.POINTER(_vp)]),
+    "volume_gpu_generate_noise": (C.c_int, [C.c_int, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "volume_gpu_render": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs)]),
+    "volume_gpu_render_device": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs), _vp]),
+    "volly_gpu_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "volly_gpu_kernel_time": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "volly_gpu_read_voxels": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
+    "volly_gpu_scene_info": (C.c_int64, [_vp, C.c_int]),
+    "volly_gpu_free": (None, [_vp]),
+    "volly_gpu_last_error": (C.c_char_p, []),
+    "volly_gpu_abi_version": (C.c_int, []),
+}
+for _name, (_res, _args) in _sig.items():
+    _fn = getattr(lib, _name)
+    _fn.restype, _fn.argtypes = _res, _args
+EXPORTS = tuple(_sig)
+
+
+class VollyError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = (lib.volly_gpu_last_error() or b"").decode()
+        super().__init__(f"{where}: error {code}: {msg}")
+
+
+def _check(rc, where):
+    if rc != VOLLY_OK:
+        raise VollyError(rc, where)
+
+
+def _frames_array(frames):
+    if isinstance(frames, FrameDesc):
+        arr = (FrameDesc * 1)()
+        arr[0] = frames
+        return arr, 1
+    if isinstance(frames, C.Array):
+        return frames, len(frames)
+    frames = list(frames)
+    arr = (FrameDesc * len(frames))()
+    for i, f in enumerate(frames):
+        arr[i] = f
+    return arr, len(frames)
+
+
+_DT = {"rgba8": np.uint32, "hit_index": np.uint32, "steps_lo": np.uint32, "steps_hi": np.uint32, "depth": np.float32}
+
+
+class GpuScene:
+    """A scene resident in HBM (volume_gpu_upload / svo_gpu_upload)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def upload_dense(cls, target, low=None, device=0):
+        h = _vp()
+        _check(lib.volume_gpu_upload(device, C.byref(target), C.byref(low) if low is not None else None, C.byref(h)),
+               "volume_gpu_upload")
+        return cls(h)
+
+    @classmethod
+    def upload_svo(cls, svo, low=None, device=0):
+        h = _vp()
+        _check(lib.svo_gpu_upload(device, C.byref(svo), C.byref(low) if low is not None else None, C.byref(h)),
+               "svo_gpu_upload")
+        return cls(h)
+
+    @classmethod
+    def noise(cls, res, seed=1, threshold=1 << 24, device=0):
+        h = _vp()
+        _check(lib.volume_gpu_generate_noise(device, res, seed, threshold, C.byref(h)), "volume_gpu_generate_noise")
+        return cls(h)
+
+    def info(self, what):
+        return int(lib.volly_gpu_scene_info(self._h, what))
+
+    @property
+    def size(self):
+        return (self.info(0), self.info(1), self.info(2))
+
+    @property
+    def low_size(self):
+        n = self.info(5)
+        return (n, n, n)
+
+    def render(self, frames, planes=PLANES):
+        """Synchronous render to host memory: dict plane -> (n_frames, tile_h, tile_w) array."""
+        arr, n = _frames_array(frames)
+        th, tw = arr[0].tile_h, arr[0].tile_w
+        res = {p: np.empty((n, th, tw), _DT[p]) for p in planes}
+        outs = Outputs(*[res[p].ctypes.data if p in res else None for p in PLANES])
+        _check(lib.volume_gpu_render(self._h, arr, n, C.byref(outs)), "volume_gpu_render")
+        return res
+
+    def render_device(self, frames, ptrs, stream=None):
+        """Asynchronous render into device memory.  ptrs: dict plane -> device pointer (int)."""
+        arr, n = _frames_array(frames)
+        outs = Outputs(*[ptrs.get(p) for p in PLANES])
+        _check(lib.volume_gpu_render_device(self._h, arr, n, C.byref(outs), stream), "volume_gpu_render_device")
+
+    def set_profiling(self, on=True):
+        _check(lib.volly_gpu_set_profiling(self._h, int(on)), "volly_gpu_set_profiling")
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_int()
+        _check(lib.volly_gpu_kernel_time(self._h, C.byref(ms), C.byref(n)), "volly_gpu_kernel_time")
+        return ms.value, n.value
+
+    def read_voxels(self, first, count):
+        out = np.empty((count, 8), np.uint8)
+        _check(lib.volly_gpu_read_voxels(self._h, first, count, out.ctypes.data), "volly_gpu_read_voxels")
+        return out
+
+    def close(self):
+        if self._h:
+            lib.volly_gpu_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

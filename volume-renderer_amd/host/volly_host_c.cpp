@@ -1,0 +1,189 @@
+// volly_host_c.cpp -- extern "C" wrappers of the host scene pipeline (include/volly_host.h).
+#include "../../include/volly_host.h"
+#include "volly_scene.h"
+#include "tricube.h"
+
+#include <memory>
+#include <string>
+
+using namespace volly;
+
+struct volly_host_scene {
+    std::unique_ptr<VoxelMap> map;
+    std::unique_ptr<VolumeStore<Voxel>> target, low;
+    std::unique_ptr<SparseVoxelOctree> svo;
+};
+
+struct volly_host_lod_set {
+    std::unique_ptr<Vol_LOD_Set> set;
+};
+
+namespace {
+thread_local std::string g_err;
+
+VolumeStore<Voxel> *reduce_any(const VolumeStore<Voxel> *hi, int f)
+{
+    ivec3 ls((hi->size.x + f - 1) / f, (hi->size.y + f - 1) / f, (hi->size.z + f - 1) / f);
+    auto *lo = new VolumeStore<Voxel>(ls);
+    size_t i = 0;
+    for (int z = 0; z < hi->size.z; ++z)
+        for (int y = 0; y < hi->size.y; ++y)
+            for (int x = 0; x < hi->size.x; ++x, ++i)
+                if (hi->data[i].rgba[3] > 0) {
+                    Voxel &d = lo->sample(x / f, y / f, z / f);
+                    if (d.rgba[3] == 0) d = hi->data[i];
+                }
+    return lo;
+}
+
+VolumeStore<Voxel> *copy_grid(const volly_dense_desc *d)
+{
+    auto *v = new VolumeStore<Voxel>(ivec3(d->sx, d->sy, d->sz));
+    std::memcpy((void *)v->data, d->voxels, v->count() * sizeof(Voxel));
+    return v;
+}
+} // namespace
+
+extern "C" {
+
+const char *volly_host_last_error(void) { return g_err.c_str(); }
+
+volly_host_scene *volly_host_scene_from_mesh(const char *path, int32_t res, int32_t flags, int32_t n_threads)
+{
+    g_err.clear();
+    if (!path || res < 8 || (res % 4) != 0) { g_err = "volly_host_scene_from_mesh: need a path and res >= 8, multiple of 4"; return nullptr; }
+    std::string err;
+    std::unique_ptr<Polyhedron> poly(readMeshFile(path, &err));
+    if (!err.empty() || poly->verts.empty() || poly->inds.empty()) {
+        g_err = err.empty() ? std::string("empty mesh: ") + path : err;
+        return nullptr;
+    }
+    auto s = std::make_unique<volly_host_scene>();
+    normalizePoly(poly.get());                                                 // main.cpp:27
+    s->map.reset(rasterizeVoxelMapFromPoly(poly.get(), res, n_threads));       // main.cpp:28
+    s->low.reset(volumeFromVoxelMap(s->map.get(), res / 4, 2));                // main.cpp:33
+    if (flags & VOLLY_SCENE_DENSE) s->target.reset(volumeFromVoxelMap(s->map.get(), res, 0));   // main.cpp:32
+    if (flags & VOLLY_SCENE_SVO) s->svo = std::make_unique<SparseVoxelOctree>(s->map.get(), res);
+    return s.release();
+}
+
+volly_host_scene *volly_host_scene_sphere(int32_t res, const uint8_t fill[8], int32_t flags)
+{
+    g_err.clear();
+    if (res < 4 || !fill) { g_err = "volly_host_scene_sphere: bad arguments"; return nullptr; }
+    auto s = std::make_unique<volly_host_scene>();
+    Voxel v;
+    std::memcpy(&v, fill, 8);
+    s->target = std::make_unique<VolumeStore<Voxel>>(ivec3(res, res, res));
+    s->target->fillSphere(v);
+    s->low.reset(reduce_any(s->target.get(), 4));
+    if (flags & VOLLY_SCENE_SVO) s->svo = std::make_unique<SparseVoxelOctree>(s->target.get());
+    return s.release();
+}
+
+volly_host_scene *volly_host_scene_from_dense(const volly_dense_desc *target, const volly_dense_desc *low, int32_t flags)
+{
+    g_err.clear();
+    if (!target || !target->voxels || target->sx < 1 || target->sy < 1 || target->sz < 1) {
+        g_err = "volly_host_scene_from_dense: bad target";
+        return nullptr;
+    }
+    auto s = std::make_unique<volly_host_scene>();
+    s->target.reset(copy_grid(target));
+    if (low && low->voxels) s->low.reset(copy_grid(low));
+    if (flags & VOLLY_SCENE_SVO) s->svo = std::make_unique<SparseVoxelOctree>(s->target.get());
+    return s.release();
+}
+
+int volly_host_scene_target(const volly_host_scene *s, volly_dense_desc *out)
+{
+    if (!s || !out) return VOLLY_E_ARG;
+    if (!s->target) return VOLLY_E_UNSUPPORTED;
+    *out = s->target->desc();
+    return VOLLY_OK;
+}
+
+int volly_host_scene_low(const volly_host_scene *s, volly_dense_desc *out)
+{
+    if (!s || !out) return VOLLY_E_ARG;
+    if (!s->low) return VOLLY_E_UNSUPPORTED;
+    *out = s->low->desc();
+    return VOLLY_OK;
+}
+
+int volly_host_scene_svo(const volly_host_scene *s, volly_svo_desc *out)
+{
+    if (!s || !out) return VOLLY_E_ARG;
+    if (!s->svo) return VOLLY_E_UNSUPPORTED;
+    *out = s->svo->desc();
+    return VOLLY_OK;
+}
+
+int64_t volly_host_scene_lod_count(const volly_host_scene *s, int32_t lod)
+{
+    if (!s || !s->map) return -1;
+    if (lod < 0 || (size_t)lod >= s->map->lod.size()) return 0;
+    return (int64_t)s->map->lod[(size_t)lod].cell.size();
+}
+
+void volly_host_scene_free(volly_host_scene *s) { delete s; }
+
+volly_host_lod_set *volly_host_lod_set_load(const char *path, int32_t sLowR, int32_t lowR, int32_t medR, int32_t highR)
+{
+    g_err.clear();
+    if (!path || sLowR < 1 || lowR < 1 || medR < 1) { g_err = "volly_host_lod_set_load: bad arguments"; return nullptr; }
+    auto s = std::make_unique<volly_host_lod_set>();
+    s->set = std::make_unique<Vol_LOD_Set>(path, 0, sLowR, lowR, medR, highR);
+    if (!s->set->error.empty()) { g_err = s->set->error; return nullptr; }
+    return s.release();
+}
+
+int volly_host_lod_set_grid(const volly_host_lod_set *s, int32_t which, volly_dense_desc *out)
+{
+    if (!s || !out || which < 0 || which > 3) return VOLLY_E_ARG;
+    if (!s->set->arr[which]) return VOLLY_E_UNSUPPORTED;
+    *out = s->set->arr[which]->desc();
+    return VOLLY_OK;
+}
+
+void volly_host_lod_set_free(volly_host_lod_set *s) { delete s; }
+
+void volly_host_frame_from_camera(const float view[16], const float cam_pos[3], const int32_t size_hi[3],
+                                  const int32_t size_lo[3], int32_t width, int32_t height, volly_frame_desc *out)
+{
+    mat4 v;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) v[c][r] = view[c * 4 + r];
+    frame_from_camera(v, vec3(cam_pos[0], cam_pos[1], cam_pos[2]), ivec3(size_hi[0], size_hi[1], size_hi[2]),
+                      ivec3(size_lo[0], size_lo[1], size_lo[2]), width, height, out);
+}
+
+void volly_host_look_at(const float eye[3], const float center[3], const float up[3], float view[16])
+{
+    mat4 v = look_at(vec3(eye[0], eye[1], eye[2]), vec3(center[0], center[1], center[2]), vec3(up[0], up[1], up[2]));
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) view[c * 4 + r] = v[c][r];
+}
+
+void volly_host_cam_dir_from_mouse(int32_t mouse_x, int32_t mouse_y, int32_t win_x, int32_t win_y, float cam_dir[3])
+{
+    vec3 d = cam_dir_from_mouse(mouse_x, mouse_y, win_x, win_y);
+    cam_dir[0] = d.x; cam_dir[1] = d.y; cam_dir[2] = d.z;
+}
+
+void volly_host_orbit_camera(int32_t k, int32_t n, float radius, float cam_pos[3], float view[16])
+{
+    vec3 p;
+    mat4 v;
+    orbit_camera(k, n, radius, &p, &v);
+    cam_pos[0] = p.x; cam_pos[1] = p.y; cam_pos[2] = p.z;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) view[c * 4 + r] = v[c][r];
+}
+
+int volly_host_tricube(const float t[9])
+{
+    return triangle_touches_unit_cube({t[0], t[1], t[2]}, {t[3], t[4], t[5]}, {t[6], t[7], t[8]}) ? 0 : 1;
+}
+
+} // extern "C"
