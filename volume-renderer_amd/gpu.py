@@ -9,6 +9,15 @@ import numpy as np
 
 from ._abi import (LIB_DIR, DenseDesc, SvoDesc, FrameDesc, Outputs, PLANES, VOLLY_OK)
 
+try:
+    # torch ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
+    # process do not share the GPU ("No HIP GPUs are available" for the second one).
+    # Loading torch first makes libvolly_gpu.so bind to the runtime torch already loaded
+    # (same SONAME).  Without torch the library uses the system ROCm runtime.
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 _path = os.path.join(LIB_DIR, "libvolly_gpu.so")
 if not os.path.exists(_path):
     raise ImportError(f"{_path} is missing: the HIP extension must be built (make gpu / __graft_entry__.build()); "
