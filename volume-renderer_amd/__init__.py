@@ -9,6 +9,6 @@ Python here is plumbing only (ctypes over the two shared libraries):
   host  -> lib/libvolly_host.so  scene pipeline in C++ (mesh, voxelizer, octree, camera)
   gpu   -> lib/libvolly_gpu.so   HIP kernels + C-ABI; import fails loudly if it is missing.
 """
-from . import host, gpu   # noqa: F401
+from . import host, gpu, shard   # noqa: F401
 from .host import HostScene, LodSet, frame_from_camera, orbit_camera, look_at, orbit_frames  # noqa: F401
 from .gpu import GpuScene, VollyError  # noqa: F401
