@@ -19,7 +19,7 @@ HOST_HDR := $(PKG)/host/volly_scene.h $(PKG)/host/vollymath.h $(PKG)/host/tricub
 
 FPFLAGS  := -ffp-contract=off -fno-fast-math
 
-all: gpu host oracle ref
+all: gpu host oracle ref examples
 
 gpu: $(LIBDIR)/libvolly_gpu.so
 host: $(LIBDIR)/libvolly_host.so
@@ -46,7 +46,14 @@ oracle/_ref/libtricube_ref.so: oracle/tricube_ref_export.cpp $(REF)/triangleCube
 	@mkdir -p oracle/_ref
 	$(CXX) -O3 -mavx -std=c++14 -fPIC -shared $(FPFLAGS) -I$(REF) -o $@ oracle/tricube_ref_export.cpp
 
-clean:
-	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref
+examples: examples/volly_headless
 
-.PHONY: all gpu host oracle ref clean
+# reference-style main loop on top of the C-ABI (links both libraries; rpath keeps it relocatable with the tree)
+examples/volly_headless: examples/volly_headless.cpp $(PKG)/host/volly_state.h $(LIBDIR)/libvolly_host.so $(LIBDIR)/libvolly_gpu.so
+	$(CXX) -O2 -std=c++17 $(FPFLAGS) -Wall -Wextra -o $@ examples/volly_headless.cpp \
+	    -L$(LIBDIR) -lvolly_host -lvolly_gpu -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath-link,/opt/rocm/lib
+
+clean:
+	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref examples/volly_headless
+
+.PHONY: all gpu host oracle ref examples clean

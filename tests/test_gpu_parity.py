@@ -249,3 +249,31 @@ def test_config2_dragon512_full_frame(vra, ora):
         assert (want["hit_index"] != MISS).sum() > 50000
         assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"dragon512 view {i}")
     gpu.close()
+
+
+def test_reference_style_state_example(vra, ora, tmp_path):
+    """examples/volly_headless: the reference's main loop on volly::State (C++ adapter over
+    the C-ABI): galleon.ply, the default 16/32/128/256 LoD set, 400x300 target (main.h:112).
+    Its last frame must equal the oracle's render of the same State."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "examples", "volly_headless")
+    if not os.path.exists(exe):
+        pytest.fail("examples/volly_headless is not built (make examples)")
+    mesh = os.path.join(ASSETS, "galleon.ply")
+    for lod, cam in ((2, (0.9, -0.3, 0.6)), (0, (0.0, 0.0, 0.0))):
+        ppm = tmp_path / f"out{lod}.ppm"
+        r = subprocess.run([exe, mesh, str(lod), "3", str(ppm), "300", "500"] + [str(c) for c in cam],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "raycasts per second" in r.stdout
+        raw = ppm.read_bytes()
+        assert raw.startswith(b"P6\n400 300\n255\n")
+        got = np.frombuffer(raw[len(b"P6\n400 300\n255\n"):], np.uint8).reshape(300, 400, 3)
+        ls = vra.LodSet(mesh)
+        tgt, low = ls.grid(lod), ls.grid(1)
+        view = vra.look_at((0, 0, 0), vra.host.cam_dir_from_mouse(300 + 14, 500), (0, 0, -1))
+        f = vra.frame_from_camera(view, cam, (tgt.sx,) * 3, (low.sx,) * 3, 400, 300)
+        want = ora.render_frame(f, low=low, target=tgt)["rgba8"].view(np.uint8).reshape(300, 400, 4)
+        assert want[..., 0].min() == 255
+        assert np.array_equal(got, want[..., 1:4])

@@ -1,0 +1,160 @@
+// volly_state.h -- C++ adapter that keeps the reference's class API on top of the C-ABI.
+//
+// volly::State mirrors the reference's State (main.h:89-121): same fields, same
+// accessors, and raycastOntoScreen() with the same contract -- fill
+// data_stream[x + y*W] with u8vec4(255, r, g, b) pixels for the current volume,
+// LoD and camera (main.cpp:197-291).  Its body no longer loops over pixels: it
+// computes the per-frame constants exactly as main.cpp:201-249 does
+// (volly::frame_from_camera) and hands them to volume_gpu_render.  SDL is gone:
+// the caller owns the pixel buffer that Texture_SDL::data_stream used to point at
+// (main.h:33), and feeds mouse / key state directly to resolveUserInput.
+//
+// Header only; link with libvolly_host.so and libvolly_gpu.so.
+#ifndef VOLLY_STATE_H
+#define VOLLY_STATE_H
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "volly_scene.h"
+#include "../../include/volly_gpu.h"
+
+namespace volly {
+namespace gpu {
+
+// RAII handle of one uploaded (target grid, low grid) pair
+class Scene {
+public:
+    Scene() = default;
+    Scene(const Scene &) = delete;
+    Scene &operator=(const Scene &) = delete;
+    Scene(Scene &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    Scene &operator=(Scene &&o) noexcept { std::swap(h_, o.h_); return *this; }
+    ~Scene() { volly_gpu_free(h_); }
+    volly_gpu_scene *get() const { return h_; }
+    explicit operator bool() const { return h_ != nullptr; }
+
+    static Scene upload(const VolumeStore<Voxel> &target, const VolumeStore<Voxel> *low, int device = 0)
+    {
+        Scene s;
+        volly_dense_desc t = target.desc(), l{};
+        if (low) l = low->desc();
+        check(volume_gpu_upload(device, &t, low ? &l : nullptr, &s.h_), "volume_gpu_upload");
+        return s;
+    }
+    static Scene upload(const SparseVoxelOctree &svo, const VolumeStore<Voxel> *low, int device = 0)
+    {
+        Scene s;
+        volly_svo_desc t = svo.desc();
+        volly_dense_desc l{};
+        if (low) l = low->desc();
+        check(svo_gpu_upload(device, &t, low ? &l : nullptr, &s.h_), "svo_gpu_upload");
+        return s;
+    }
+    static void check(int rc, const char *where)
+    {
+        if (rc != VOLLY_OK) throw std::runtime_error(std::string(where) + ": " + volly_gpu_last_error());
+    }
+private:
+    volly_gpu_scene *h_ = nullptr;
+};
+
+} // namespace gpu
+
+// main.h:58-72 without SDL: scancodes are plain ints chosen by the caller
+struct KeyHandler {
+    std::map<int, bool> keysDown;
+    bool getIfKeyDown(int scan) { return keysDown[scan]; }
+    void setKeyState(int scan, bool state = true) { keysDown[scan] = state; }
+};
+
+enum Key { KEY_W, KEY_A, KEY_S, KEY_D, KEY_LCTRL, KEY_LSHIFT, KEY_M, KEY_COMMA, KEY_PERIOD, KEY_SLASH, KEY_0 /* .. KEY_0+8 */ };
+
+// main.h:89-121
+struct State {
+    std::vector<Vol_LOD_Set *> volumes;
+    int curVolume = 0, curLoD = 0;
+    int frame = 0;
+
+    vec3 camPos = vec3(0);
+    vec3 camDir = vec3(0);
+    vec3 camUp = vec3(0, 0, -1);
+    mat4 view;
+    KeyHandler keys;
+    int mouseX = 0, mouseY = 0;
+    int winSizeX = 1152, winSizeY = 864;
+    int renderTargetSizeX = 400, renderTargetSizeY = 300;
+    int device = 0;
+
+    VolumeStore<Voxel> *getCurVol() { return volumes[(size_t)curVolume]->arr[curLoD]; }
+    VolumeStore<Voxel> *getCurVol_LowLOD() { return volumes[(size_t)curVolume]->arr[1]; }
+    VolumeStore<Voxel> *getCurVol_SLowLOD() { return volumes[(size_t)curVolume]->arr[0]; }
+
+    ~State() { for (auto *v : volumes) delete v; }
+
+    // main.cpp:369-387 with the asset paths passed in
+    void initAllVolumes(const std::vector<std::string> &meshPaths)
+    {
+        for (const std::string &p : meshPaths) {
+            auto *set = new Vol_LOD_Set(p);
+            if (!set->error.empty()) { std::string e = set->error; delete set; throw std::runtime_error(e); }
+            volumes.push_back(set);
+        }
+    }
+
+    // main.cpp:389-437 (mouse -> camDir -> view; keys -> camPos, LoD, model)
+    void resolveUserInput()
+    {
+        camUp = vec3(0, 0, -1);
+        camDir = cam_dir_from_mouse(mouseX, mouseY, winSizeX, winSizeY);
+        view = look_at(vec3(0), camDir, camUp);
+        float dy = 0, dx = 0, dz = 0, speed = 0.01f;
+        if (keys.getIfKeyDown(KEY_W)) dy += 1;
+        if (keys.getIfKeyDown(KEY_A)) dx -= 1;
+        if (keys.getIfKeyDown(KEY_S)) dy -= 1;
+        if (keys.getIfKeyDown(KEY_D)) dx += 1;
+        if (keys.getIfKeyDown(KEY_LCTRL)) dz -= 1;
+        if (keys.getIfKeyDown(KEY_LSHIFT)) dz += 1;
+        camPos = camPos + (-camDir * dy) * speed;
+        vec3 right = cross(camUp, camDir);
+        camPos = camPos + (-right * dx) * speed;
+        camPos = camPos + (-camUp * dz) * speed;
+        for (int k = 0; k <= 8; ++k)
+            if (keys.getIfKeyDown(KEY_0 + k) && (size_t)k < volumes.size()) curVolume = k;
+        if (keys.getIfKeyDown(KEY_M)) curLoD = 0;
+        if (keys.getIfKeyDown(KEY_COMMA)) curLoD = 1;
+        if (keys.getIfKeyDown(KEY_PERIOD)) curLoD = 2;
+        if (keys.getIfKeyDown(KEY_SLASH)) curLoD = 3;
+    }
+
+    // main.cpp:197-291.  data_stream: renderTargetSizeX*renderTargetSizeY pixels of 4
+    // bytes, what Texture_SDL::lock() handed out (main.h:38-40).
+    void raycastOntoScreen(uint32_t *data_stream)
+    {
+        gpu::Scene &scene = sceneFor(curVolume, curLoD);
+        VolumeStore<Voxel> *hi = getCurVol(), *lo = getCurVol_LowLOD();
+        volly_frame_desc fd;
+        frame_from_camera(view, camPos, hi->size, lo->size, renderTargetSizeX, renderTargetSizeY, &fd);
+        volly_outputs out{};
+        out.rgba8 = data_stream;
+        gpu::Scene::check(volume_gpu_render(scene.get(), &fd, 1, &out), "volume_gpu_render");
+        ++frame;
+    }
+
+private:
+    std::map<std::pair<int, int>, gpu::Scene> uploaded_;
+    gpu::Scene &sceneFor(int vol, int lod)
+    {
+        auto key = std::make_pair(vol, lod);
+        auto it = uploaded_.find(key);
+        if (it == uploaded_.end())
+            it = uploaded_.emplace(key, gpu::Scene::upload(*volumes[(size_t)vol]->arr[lod], volumes[(size_t)vol]->arr[1], device)).first;
+        return it->second;
+    }
+};
+
+} // namespace volly
+#endif
