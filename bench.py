@@ -22,24 +22,41 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ORBIT_VIEWS = 4096             # SURVEY 8d config 5 orbit
 
+# BASELINE.json configs -> workload parameters (scene "noise" = volume_gpu_generate_noise, p = 1/256)
+PRESETS = {
+    1: dict(scene="teapot.off", res=128, target="svo", width=640, height=480, views=64, radius=1.0, split=False),
+    2: dict(scene="dragon.off", res=512, target="svo", width=1920, height=1080, views=16, radius=1.0, split=False),
+    3: dict(scene="noise", res=1024, target="dense", width=3840, height=2160, views=2, radius=1.1, split=False),
+    4: dict(scene="galleon.ply", res=2048, target="svo", width=7680, height=4320, views=1, radius=1.0, split=True),
+    5: dict(scene="stratocaster.ply", res=1024, target="svo", width=1920, height=1080, views=16, radius=1.2, split=False),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--views", type=int, default=16, help="orbit views per step per GPU")
-    ap.add_argument("--scene", default="dragon.off")
-    ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--radius", type=float, default=1.0)
-    ap.add_argument("--target", choices=["svo", "dense"], default="svo")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(PRESETS),
+                    help="BASELINE.json config number (default 2, the config the metric is quoted on)")
+    ap.add_argument("--views", type=int, default=None, help="orbit views per step per GPU")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--res", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--radius", type=float, default=None)
+    ap.add_argument("--target", choices=["svo", "dense"], default=None)
+    ap.add_argument("--split", action="store_true", default=None,
+                    help="one frame per step split into row bands over the ranks + gather to rank 0 (config 4)")
     ap.add_argument("--mode", choices=["beam", "naive"], default="beam",
                     help="beam = raycast_beamOpt (the reference's live path); naive = traversal from the camera")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the workload timed on the CPU oracle (0 = auto)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    for k, v in PRESETS[args.config].items():
+        if getattr(args, k, None) is None:
+            setattr(args, k, v)
+    return args
 
 
 def main():
@@ -60,34 +77,56 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    # ---- scene: host voxelization + octree build, then one upload to HBM ---------------------
+    # ---- scene: host voxelization + octree build (or device-side noise), one upload to HBM ----
     t0 = time.time()
     want_dense = args.target == "dense"
-    scene = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", args.scene), args.res, dense=want_dense,
-                                    svo=not want_dense, threads=max(1, 16 // max(1, min(world, 8))) if world > 1 else 0)
-    size_hi, size_lo = (args.res,) * 3, (args.res // 4,) * 3
-    if want_dense:
-        gpu = vra.GpuScene.upload_dense(scene.target, scene.low, device=local_rank)
+    scene = None
+    if args.scene == "noise":
+        gpu = vra.GpuScene.noise(args.res, seed=1, threshold=1 << 24, device=local_rank)      # p = 2^24 / 2^32 = 1/256
+        data = f"synthetic {args.res}^3 noise volume generated on the device (p = 1/256), synthetic orbit cameras"
     else:
-        gpu = vra.GpuScene.upload_svo(scene.svo, scene.low, device=local_rank)
+        threads = 0 if world == 1 else max(2, 16 // min(world, 8))
+        scene = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", args.scene), args.res, dense=want_dense,
+                                        svo=not want_dense, threads=threads)
+        if want_dense:
+            gpu = vra.GpuScene.upload_dense(scene.target, scene.low, device=local_rank)
+        else:
+            gpu = vra.GpuScene.upload_svo(scene.svo, scene.low, device=local_rank)
+        data = f"bundled asset ({args.scene}) voxelized on the host, synthetic orbit cameras"
+    size_hi, size_lo = (args.res,) * 3, (args.res // 4,) * 3
     setup_s = time.time() - t0
 
     W, H, B = args.width, args.height, args.views
     naive = args.mode == "naive"
-    planes = {p: torch.empty((B, H, W), dtype=torch.float32 if p == "depth" else torch.int32, device=dev)
-              for p in ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")}
+    split = bool(args.split)
+    if split:
+        B = 1
+        y0, rows = vra.shard.band_rows(H, rank, world)
+    else:
+        y0, rows = 0, H
+    names = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")
+    planes = {p: torch.empty((B, rows, W), dtype=torch.float32 if p == "depth" else torch.int32, device=dev)
+              for p in names}
     ptrs = {p: t.data_ptr() for p, t in planes.items()}
     stream = torch.cuda.current_stream(dev)
 
     def step_frames(step):
-        # global view index: steps advance through the orbit, ranks interleave (k = rank mod world)
-        ks = [((step * B + i) * world + rank) % ORBIT_VIEWS for i in range(B)]
-        return vra.orbit_frames(ks, ORBIT_VIEWS, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
+        if split:      # every rank renders its row band of the SAME view
+            ks = [step % ORBIT_VIEWS]
+        else:          # ranks interleave through the orbit: view k goes to rank k mod world
+            ks = [((step * B + i) * world + rank) % ORBIT_VIEWS for i in range(B)]
+        frames = vra.orbit_frames(ks, ORBIT_VIEWS, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
+        if split:
+            frames[0] = frames[0].band(y0, rows)
+        return frames
 
     all_frames = [step_frames(s) for s in range(args.warmup + args.steps)]
+    assembled = [None]
 
     def run(frames):
         gpu.render_device(frames, ptrs, stream=stream.cuda_stream)
+        if split:      # frame assembly on rank 0: the one collective of the path (RCCL gather over xGMI)
+            assembled[0] = vra.shard.gather_bands(planes["rgba8"][0], H, W, rank, world, dist, dst=0)
 
     for s in range(args.warmup):
         run(all_frames[s])
@@ -117,32 +156,34 @@ def main():
     # B_ray = 8*(steps_lo + steps_hi) + 8*[hit] + 4 (pixel) + 16 (aux planes)
     alg_bytes = 0
     sum_lo = sum_hi = hits = 0
-    rays_per_step = B * H * W
+    rays_per_launch = B * rows * W
     for s in range(args.warmup, args.warmup + args.steps):
-        run(all_frames[s])
+        gpu.render_device(all_frames[s], ptrs, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         lo = int(planes["steps_lo"].sum(dtype=torch.int64).item())
         hi = int(planes["steps_hi"].sum(dtype=torch.int64).item())
         h = int((planes["hit_index"] != -1).sum().item())
         sum_lo += lo; sum_hi += hi; hits += h
-        alg_bytes += 8 * (lo + hi) + 8 * h + 20 * rays_per_step
+        alg_bytes += 8 * (lo + hi) + 8 * h + 20 * rays_per_launch
 
-    total_rays = rays_per_step * args.steps * world
-    mrays = total_rays / elapsed / 1e6
+    rays_per_step = (H * W) if split else (B * H * W * world)       # whole job, all ranks
+    mrays = rays_per_step * args.steps / elapsed / 1e6
+    par = (f"one frame split into {world} row bands + gather of rgba8 to rank 0" if split
+           else f"view-parallel x{world}, scene replicated, no collective")
     out = {
         "metric": "primary Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "bundled asset (dragon.off) voxelized on the host, synthetic orbit cameras",
+        "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
+        "dtype": "f32", "data": data,
         "config": {"workload": f"{args.scene} at {args.res}^3 {args.target} target, low grid {args.res // 4}^3, "
-                               f"{W}x{H} frames, {args.mode} mode (BASELINE config 2)",
-                   "views_per_step_per_gpu": B, "rays_per_step_per_gpu": rays_per_step,
-                   "orbit_radius": args.radius, "planes_written": 5, "parallelism": f"view-parallel x{world}, scene replicated",
-                   "mean_steps_lo": round(sum_lo / (rays_per_step * args.steps), 3),
-                   "mean_steps_hi": round(sum_hi / (rays_per_step * args.steps), 3),
-                   "hit_fraction": round(hits / (rays_per_step * args.steps), 4),
-                   "scene_setup_s": round(setup_s, 2)},
+                               f"{W}x{H} frames, {args.mode} mode (BASELINE config {args.config})",
+                   "views_per_step_per_gpu": B, "rays_per_step": rays_per_step,
+                   "orbit_radius": args.radius, "planes_written": 5, "parallelism": par,
+                   "mean_steps_lo": round(sum_lo / (rays_per_launch * args.steps), 3),
+                   "mean_steps_hi": round(sum_hi / (rays_per_launch * args.steps), 3),
+                   "hit_fraction": round(hits / (rays_per_launch * args.steps), 4),
+                   "scene_setup_s": round(setup_s, 2), "scene_device_mib": gpu.info(7)},
     }
     if launches:
         avg_ms = kern_ms / launches
@@ -150,8 +191,8 @@ def main():
         achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
+        if os.path.exists(tpath) and args.config == 2 and args.mode == "beam" and not split:
+            try:     # measured with rocprofv3 --pmc on this same default workload (see the file's comment)
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -162,7 +203,7 @@ def main():
                            "algorithmic_bytes_per_launch": int(alg_per_launch)}
 
     # ---- CPU baseline: the oracle, one thread (the reference is single threaded), bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and scene is not None:
         from __graft_entry__ import load_oracle
         ora = load_oracle()
         n_cpu = args.cpu_frames or max(1, min(8, int(round(16e6 / (W * H)))))
@@ -172,8 +213,8 @@ def main():
         for i in range(n_cpu):
             ora.render_frame(frames[i % B], threads=1, **kw)
         cpu_s = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(n_cpu * W * H / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
-                               "sample": f"{n_cpu} of the {B} frames of the first timed step ({n_cpu * W * H} rays), "
+        out["cpu_baseline"] = {"value": round(n_cpu * rows * W / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                               "sample": f"{n_cpu} frame(s) of the first timed step ({n_cpu * rows * W} rays), "
                                          f"scalar C oracle, gcc -O3 -mavx -ffp-contract=off, {cpu_s:.1f} s"}
     if rank == 0:
         print(json.dumps(out), flush=True)
