@@ -48,6 +48,15 @@ oracle/_ref/libtricube_ref.so: oracle/tricube_ref_export.cpp $(REF)/triangleCube
 
 examples: examples/volly_headless
 
+# alternative builds of the kernels for A/B measurement (profiles/ab_bench.py); never loaded by the product
+VARDIR := $(LIBDIR)/variants
+variants:
+	@mkdir -p $(VARDIR)
+	for v in checked:-DVK_FAST_DDA=0 aos:-DVK_AOS_SAMPLE=1 linear:-DVK_LINEAR_TILE=1 xcd:-DVK_XCD_REMAP=1 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 'rootwalk_nolds:-DVK_SVO_TABLE=0 -DVK_LDS_TOP=0'; do \
+	  n=$${v%%:*}; f="$${v#*:}"; \
+	  $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(FPFLAGS) -Iinclude $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(PKG)/csrc/volly_gpu.hip || exit 1; \
+	done
+
 # reference-style main loop on top of the C-ABI (links both libraries; rpath keeps it relocatable with the tree)
 examples/volly_headless: examples/volly_headless.cpp $(PKG)/host/volly_state.h $(LIBDIR)/libvolly_host.so $(LIBDIR)/libvolly_gpu.so
 	$(CXX) -O2 -std=c++17 $(FPFLAGS) -Wall -Wextra -o $@ examples/volly_headless.cpp \
@@ -56,4 +65,4 @@ examples/volly_headless: examples/volly_headless.cpp $(PKG)/host/volly_state.h $
 clean:
 	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref examples/volly_headless
 
-.PHONY: all gpu host oracle ref examples clean
+.PHONY: all gpu host oracle ref examples variants clean

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -108,8 +109,16 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
     hipLaunchKernelGGL(vk::build_occupancy, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, vox, sx, sy, sz, d.nbx, d.nby,
                        d.nbz, occ);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
     d.occ = occ;
+    d.nrx = (d.nbx + 3) / 4; d.nry = (d.nby + 3) / 4; d.nrz = (d.nbz + 3) / 4;
+    const size_t nr = (size_t)d.nrx * d.nry * d.nrz;
+    uint64_t *occ2 = nullptr;
+    if ((rc = dev_alloc(s, (void **)&occ2, nr * 8))) return rc;
+    hipLaunchKernelGGL(vk::build_occupancy2, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, 0, occ, d.nbx, d.nby, d.nbz, d.nrx,
+                       d.nry, d.nrz, occ2);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    d.occ2 = occ2;
     *out = d;
     return VOLLY_OK;
 }
@@ -243,6 +252,7 @@ int svo_gpu_upload(int device, const volly_svo_desc *svo, const volly_dense_desc
         return fail(VOLLY_E_ARG, "svo_gpu_upload: null octree");
     if (svo->depth < 1 || svo->depth > 13 || svo->res < 1 || svo->res > (1 << svo->depth))
         return fail(VOLLY_E_ARG, "svo_gpu_upload: need 1 <= depth <= 13 and 1 <= res <= 2^depth");
+    if (svo->n_nodes >= 0x80000000u) return fail(VOLLY_E_ARG, "svo_gpu_upload: more than 2^31 nodes");
     // The kernel trusts the tree: check that every child reference stays inside the
     // arrays, points forward (breadth-first order) and that leaves sit exactly at
     // level 1, so a walk from the root ends after at most `depth` nodes.
@@ -286,6 +296,20 @@ int svo_gpu_upload(int device, const volly_svo_desc *svo, const volly_dense_desc
         s->svo.depth = svo->depth; s->svo.res = svo->res; s->svo.fres = (float)svo->res;
         s->svo.cap = 4u * (uint32_t)(3 * svo->res) + 8u;
         s->target.sx = s->target.sy = s->target.sz = svo->res;
+        // direct-index table of the upper levels: cells of 2^tshift voxels, at most 128^3 entries
+        int tbits = std::min(std::max(svo->depth - 3, 0), 7);
+        if (const char *e = std::getenv("VOLLY_SVO_TABLE_BITS")) tbits = std::min(std::max(std::atoi(e), 0), std::min(svo->depth - 1, 8));
+        s->svo.tbits = tbits;
+        s->svo.tshift = svo->depth - tbits;
+        const size_t nt = (size_t)1 << (3 * tbits);
+        uint32_t *table = nullptr;
+        rc = dev_alloc(s, (void **)&table, nt * 4);
+        if (!rc) {
+            hipLaunchKernelGGL(vk::build_svo_table, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, nodes, svo->depth, tbits,
+                               s->svo.tshift, table);
+            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(VOLLY_E_HIP, "build_svo_table failed");
+            s->svo.table = table;
+        }
     }
     if (!rc && low) {
         rc = make_dense(s, low->sx, low->sy, low->sz, low->voxels, nullptr, &s->low);

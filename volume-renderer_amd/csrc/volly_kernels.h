@@ -23,19 +23,54 @@
 #include <stdint.h>
 #include "volly_gpu.h"
 
+// Build-time switches.  The shipped library is built with the defaults; the others
+// exist so that each design choice can be measured against its alternative in one
+// process (profiles/ab_bench.py, Makefile target `variants`):
+//   VK_FAST_DDA=0     always use the fully checked DDA loop
+//   VK_OCC_LEVELS=1   one occupancy level (4^3 bricks) instead of two (bricks + 16^3 regions)
+//   VK_SVO_TABLE=0    locate octree cells by walking down from the root (top levels in LDS)
+//                     instead of starting at the direct-index table of the upper levels
+//   VK_AOS_SAMPLE=1   sample the reference's 8-byte voxels at every step (no occupancy bricks)
+//   VK_LINEAR_TILE=1  a wavefront covers 64x1 pixels instead of 8x8
+//   VK_LDS_TOP=0      do not stage the top of the octree in LDS
+//   VK_XCD_REMAP=1    give each XCD (blockIdx % 8) one contiguous range of pixel blocks
+#ifndef VK_FAST_DDA
+#define VK_FAST_DDA 1
+#endif
+#ifndef VK_OCC_LEVELS
+#define VK_OCC_LEVELS 2             // 1: bricks only; 2: bricks + one word per 4x4x4 bricks
+#endif
+#ifndef VK_SVO_TABLE
+#define VK_SVO_TABLE 1              // 0: walk down from the root at every iteration (top levels from LDS)
+#endif
+#ifndef VK_AOS_SAMPLE
+#define VK_AOS_SAMPLE 0
+#endif
+#ifndef VK_LINEAR_TILE
+#define VK_LINEAR_TILE 0
+#endif
+#ifndef VK_LDS_TOP
+#define VK_LDS_TOP 1
+#endif
+#ifndef VK_XCD_REMAP
+#define VK_XCD_REMAP 0
+#endif
+
 namespace vk {
 
 constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
 constexpr int kBlockW = 32;         // workgroup covers 32 x 8 pixels
 constexpr int kBlockH = 8;
 constexpr int kThreads = 256;
-constexpr int kTopNodes = 585;      // octree levels 0..3 (1 + 8 + 64 + 512 nodes) staged in LDS
+constexpr int kTopNodes = VK_LDS_TOP ? 585 : 1;   // octree levels 0..3 (1 + 8 + 64 + 512 nodes) staged in LDS
 
 struct DenseDev {
     const uint64_t *occ;            // one word per 4x4x4 brick, bit = x&3 | (y&3)<<2 | (z&3)<<4
+    const uint64_t *occ2;           // one word per 4x4x4 bricks (16^3 voxels): bit set iff that brick has a voxel
     const uint2 *vox;               // the reference's 8-byte voxels, x + sx*(y + sy*z)
     int sx, sy, sz;
     int nbx, nby, nbz;              // bricks per axis
+    int nrx, nry, nrz;              // 16^3 regions per axis
     float fsx, fsy, fsz;
     uint32_t cap;                   // iteration cap 4*(sx+sy+sz)+8 (the reference has none, main.cpp:121)
 };
@@ -43,6 +78,8 @@ struct DenseDev {
 struct SvoDev {
     const uint2 *nodes;             // .x = child_offset, .y = valid_mask | leaf_mask<<8
     const uint2 *leaves;
+    const uint32_t *table;          // upper levels flattened: (2^tbits)^3 entries, see build_svo_table
+    int tbits, tshift;              // table cell = octree cell of 2^tshift voxels; tbits + tshift = depth
     uint32_t n_nodes;
     int depth, res;
     float fres;
@@ -128,7 +165,9 @@ struct Hit {
 // The reference tests roundPos = (int)curPlusEpsilon against [0,size): for the
 // x86 conversion (truncation; NaN / out of range -> INT_MIN) that is exactly
 // -1 < curPlusEpsilon < size, NaN failing, which is what is tested here.
-__device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+// This is the fully checked loop: it is right for every input, including direction
+// components that are zero, denormal or NaN (1/0 = inf, 0*inf = NaN inside the DDA).
+__device__ __forceinline__ Hit trace_dense_checked(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
     Hit h;
     enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
@@ -144,6 +183,15 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
         if (h.steps >= g.cap) break;
         int x = (int)px, y = (int)py, z = (int)pz;       // truncation toward zero, like glm::ivec4(vec4)
         ++h.steps;
+#if VK_AOS_SAMPLE
+        (void)last_brick; (void)bits;
+        const uint32_t idx = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
+        if ((g.vox[idx].x >> 24) != 0) {                 // VolumeStore::sample + rgba.a > 0, main.cpp:137-140
+            h.index = idx;
+            h.payload = idx;
+            break;
+        }
+#else
         int brick = (x >> 2) + g.nbx * ((y >> 2) + g.nby * (z >> 2));
         if (brick != last_brick) {
             bits = g.occ[brick];
@@ -155,15 +203,132 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
             h.payload = h.index;
             break;
         }
+#endif
         advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
     }
     return h;
 }
 
+// A ray is "regular" when every direction component is a normal float of magnitude
+// >= 2^-100 (so 1/d is finite).  For such a ray, once one bounds check has passed,
+// every quantity of the DDA stays finite and each step moves every coordinate by at
+// most one cell; the loop below relies on both.
+__device__ __forceinline__ bool ray_is_regular(const Ray &r)
+{
+    const float lo = 7.9e-31f, hi = 2.0f;
+    float ax = fabsf(r.dx), ay = fabsf(r.dy), az = fabsf(r.dz);
+    return (ax >= lo) & (ax <= hi) & (ay >= lo) & (ay <= hi) & (az >= lo) & (az <= hi);     // NaN fails
+}
+
+__device__ __forceinline__ bool grid_is_regular(const DenseDev &g)
+{
+    // whole 16^3 regions only (none straddles the grid's upper faces) and coordinates that fit 10 bits
+    return ((g.sx | g.sy | g.sz) & 15) == 0 && g.sx <= 1024 && g.sy <= 1024 && g.sz <= 1024;
+}
+
+// bit index x&3 | (y&3)<<2 | (z&3)<<4 of a cell packed as x | y<<10 | z<<20 (fields already
+// masked to two bits): one 24-bit multiply moves the fields at bits 0, 10, 20 to bits 18..23
+__device__ __forceinline__ uint32_t gather_bits(uint32_t masked)
+{
+    return (__umul24(masked, 0x00040404u) >> 18) & 63u;
+}
+
+__device__ __forceinline__ bool test_word(uint32_t w_lo, uint32_t w_hi, uint32_t bit)
+{
+    uint32_t w = (bit & 32u) ? w_hi : w_lo;
+    return ((w >> (bit & 31u)) & 1u) != 0;
+}
+
+// The same loop for regular rays in regular grids, with less work and far fewer loads per
+// step; every decision it takes is the one trace_dense_checked takes on the same values.
+//   * the cell is packed as c = x | y<<10 | z<<20.  Clearing the low 4 (2) bits of each field
+//     names the 16^3 region (4^3 brick) the cell lies in.  While the region does not change
+//     the cell is inside the grid (regions are whole), so the bounds test runs only on a region
+//     change.  A cell outside the grid always changes the key: a coordinate of -1 sets bits
+//     30-31, a coordinate equal to the size leaves the last region's field (a step moves each
+//     coordinate by one cell at most);
+//   * a lane keeps the region word (which of its 64 bricks hold voxels) and the word of the
+//     last non-empty brick in registers: steps through empty bricks read no memory, and a
+//     wavefront of neighbouring rays reloads only when it enters a new region or a brick with
+//     content -- the dependent-load latency that otherwise paces the loop.
+__device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
+    uint32_t last_brick = 0xFFFFFFFFu;                   // no brick yet: valid keys have bits 0-1 clear
+    uint32_t w_lo = 0, w_hi = 0;
+#if VK_OCC_LEVELS == 2
+    uint32_t last_region = 0xFFFFFFFFu;
+    uint32_t r_lo = 0, r_hi = 0;
+#endif
+    for (;;) {
+        float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
+        int x = (int)px, y = (int)py, z = (int)pz;       // truncation toward zero, saturating
+        uint32_t c = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
+        if (h.steps >= g.cap) break;
+#if VK_OCC_LEVELS == 2
+        uint32_t region = c & 0xFF0FC3F0u;
+        if (region != last_region) {
+            bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
+            if (!inside) break;
+            uint64_t bits = g.occ2[(uint32_t)(x >> 4) + (uint32_t)g.nrx * ((uint32_t)(y >> 4) + (uint32_t)g.nry * (uint32_t)(z >> 4))];
+            r_lo = (uint32_t)bits;
+            r_hi = (uint32_t)(bits >> 32);
+            last_region = region;
+        }
+        ++h.steps;
+        if (test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {          // the brick holds voxels
+#else
+        {
+#endif
+            uint32_t brick = c & 0xFFCFF3FCu;
+            if (brick != last_brick) {
+#if VK_OCC_LEVELS != 2
+                bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
+                if (!inside) break;
+#endif
+                uint64_t bits = g.occ[(uint32_t)(x >> 2) + (uint32_t)g.nbx * ((uint32_t)(y >> 2) + (uint32_t)g.nby * (uint32_t)(z >> 2))];
+                w_lo = (uint32_t)bits;
+                w_hi = (uint32_t)(bits >> 32);
+                last_brick = brick;
+            }
+#if VK_OCC_LEVELS != 2
+            ++h.steps;
+#endif
+            if (test_word(w_lo, w_hi, gather_bits(c & 0x00300C03u))) {
+                h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
+                h.payload = h.index;
+                break;
+            }
+        }
+        advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
+    }
+    return h;
+}
+
+__device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+{
+#if VK_FAST_DDA && !VK_AOS_SAMPLE
+    // one path per wavefront, so the two loops never run interleaved in a wave
+    if (grid_is_regular(g) && __all(ray_is_regular(r))) return trace_dense_regular(g, r, ox, oy, oz);
+#endif
+    return trace_dense_checked(g, r, ox, oy, oz);
+}
+
 // Octree traversal (no reference implementation: svo.cpp:14-19 is empty).  Each
-// iteration locates the sample cell by walking down from the root -- top levels
-// from LDS, the rest from L2/HBM -- and either hits a leaf voxel or steps across
-// the largest empty octree cell around the sample point.
+// iteration locates the sample cell in the tree and either hits a leaf voxel or steps
+// across the largest empty octree cell around the sample point.
+//
+// Locating a cell by walking down from the root costs one dependent load per level, and
+// that latency -- not arithmetic or bandwidth -- paces the loop.  So the upper levels are
+// flattened at upload into a direct-index table (build_svo_table): one load gives either
+// "empty cell of 2^k voxels" or the node that covers the 2^tshift cell, from which at most
+// tshift more levels remain.  A lane keeps the last table entry and its node in registers.
+// With VK_SVO_TABLE=0 the walk starts at the root with the top levels staged in LDS.
 __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, const Ray &r, float ox, float oy, float oz)
 {
     Hit h;
@@ -171,6 +336,11 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
     h.steps = 0;
     h.index = VOLLY_MISS_INDEX;
     h.payload = VOLLY_MISS_INDEX;
+#if VK_SVO_TABLE
+    (void)top;
+    uint32_t last_cell = 0xFFFFFFFFu, entry = 0;
+    uint2 entry_node = make_uint2(0u, 0u);
+#endif
     for (;;) {
         float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
         bool inside = (px > -1.0f) & (px < t.fres) & (py > -1.0f) & (py < t.fres) & (pz > -1.0f) & (pz < t.fres);
@@ -179,9 +349,24 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
         int x = (int)px, y = (int)py, z = (int)pz;
         ++h.steps;
 
-        uint2 n = top[0];
-        int sh = t.depth - 1;
         bool hit = false;
+        int sh;
+#if VK_SVO_TABLE
+        uint32_t tcell = (uint32_t)(x >> t.tshift) | ((uint32_t)(y >> t.tshift) << t.tbits) | ((uint32_t)(z >> t.tshift) << (2 * t.tbits));
+        if (tcell != last_cell) {
+            entry = t.table[tcell];
+            if (!(entry >> 31)) entry_node = t.nodes[entry];
+            last_cell = tcell;
+        }
+        uint2 n = entry_node;
+        sh = t.tshift - 1;
+        if (entry >> 31) {
+            sh = (int)(entry & 31u);                      // empty cell of 2^sh voxels, above the table's level
+        } else
+#else
+        uint2 n = top[0];
+        sh = t.depth - 1;
+#endif
         for (;;) {
             uint32_t oct = ((uint32_t)(x >> sh) & 1u) | (((uint32_t)(y >> sh) & 1u) << 1) | (((uint32_t)(z >> sh) & 1u) << 2);
             uint32_t valid = n.y & 0xFFu;
@@ -193,7 +378,11 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
                 hit = true;
                 break;
             }
+#if VK_SVO_TABLE
+            n = t.nodes[child];
+#else
             n = (child < (uint32_t)kTopNodes) ? top[child] : t.nodes[child];
+#endif
             --sh;
         }
         if (hit) {
@@ -280,10 +469,10 @@ __global__ void __launch_bounds__(kThreads)
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
               const float *__restrict__ ckpt, OutDev out)
 {
-    __shared__ uint2 top[SVO ? kTopNodes : 1];
+    __shared__ uint2 top[(SVO && !VK_SVO_TABLE) ? kTopNodes : 1];
     __shared__ uint32_t stage[5][kBlockH][kBlockW];
 
-    if (SVO) {
+    if (SVO && !VK_SVO_TABLE) {
         const uint32_t n = svo.n_nodes < (uint32_t)kTopNodes ? svo.n_nodes : (uint32_t)kTopNodes;
         for (uint32_t i = threadIdx.x; i < n; i += kThreads) top[i] = svo.nodes[i];
         __syncthreads();
@@ -291,11 +480,27 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
 
     const int f = blockIdx.z;
     const volly_frame_desc fd = frames[f];                // uniform: lives in SGPRs
+#if VK_XCD_REMAP
+    // workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD): renumber
+    // them so that each XCD renders one contiguous range of pixel blocks of the frame
+    const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned q = nblk / 8, rem = nblk % 8, xcd = lin % 8;
+    const unsigned id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + lin / 8;
+    const int bx = (int)(id % gridDim.x), by = (int)(id / gridDim.x);
+#else
+    const int bx = blockIdx.x, by = blockIdx.y;
+#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int px_in_block = wave * kTile + (lane & 7);
+#if VK_LINEAR_TILE
+    const int px_in_block = threadIdx.x & 31;             // a wavefront covers 32x2 pixels (two row segments)
+    const int py_in_block = threadIdx.x >> 5;
+    (void)wave; (void)lane;
+#else
+    const int px_in_block = wave * kTile + (lane & 7);    // a wavefront covers an 8x8 tile
     const int py_in_block = lane >> 3;
-    const int xrel = blockIdx.x * kBlockW + px_in_block;
-    const int yrel = blockIdx.y * kBlockH + py_in_block;
+#endif
+    const int xrel = bx * kBlockW + px_in_block;
+    const int yrel = by * kBlockH + py_in_block;
     const bool active = (xrel < fd.tile_w) & (yrel < fd.tile_h);
 
     uint32_t o_rgba = 255u, o_hit = VOLLY_MISS_INDEX, o_slo = 0, o_shi = 0;
@@ -344,7 +549,7 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
     stage[4][py_in_block][px_in_block] = __float_as_uint(o_depth);
     __syncthreads();
     const int wx = threadIdx.x & 31, wy = threadIdx.x >> 5;
-    const int oxr = blockIdx.x * kBlockW + wx, oyr = blockIdx.y * kBlockH + wy;
+    const int oxr = bx * kBlockW + wx, oyr = by * kBlockH + wy;
     if (oxr < fd.tile_w && oyr < fd.tile_h) {
         const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)oyr * (size_t)fd.tile_w + (size_t)oxr;
         if (out.rgba8) out.rgba8[p] = stage[0][wy][wx];
@@ -374,6 +579,44 @@ __global__ void __launch_bounds__(256) build_occupancy(const uint2 *vox, int sx,
         }
     }
     occ[b] = bits;
+}
+
+// second occupancy level: one word per 4x4x4 bricks, bit set iff the brick holds a voxel
+__global__ void __launch_bounds__(256) build_occupancy2(const uint64_t *occ, int nbx, int nby, int nbz, int nrx, int nry, int nrz,
+                                                        uint64_t *occ2)
+{
+    const size_t rg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nr = (size_t)nrx * nry * nrz;
+    if (rg >= nr) return;
+    const int rx = (int)(rg % (size_t)nrx), ry = (int)((rg / (size_t)nrx) % (size_t)nry), rz = (int)(rg / ((size_t)nrx * nry));
+    uint64_t bits = 0;
+    for (int k = 0; k < 64; ++k) {
+        const int bx = rx * 4 + (k & 3), by = ry * 4 + ((k >> 2) & 3), bz = rz * 4 + (k >> 4);
+        if (bx < nbx && by < nby && bz < nbz && occ[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * (size_t)bz)]) bits |= 1ull << k;
+    }
+    occ2[rg] = bits;
+}
+
+// Upper octree levels as a direct-index table: entry (tx,ty,tz) describes the octree cell
+// of 2^tshift voxels at (tx,ty,tz) << tshift: the index of the node covering it, or
+// 0x80000000 | k when the walk from the root ends earlier in an empty cell of 2^k voxels.
+__global__ void __launch_bounds__(256) build_svo_table(const uint2 *nodes, int depth, int tbits, int tshift, uint32_t *table)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)1 << (3 * tbits);
+    if (i >= n) return;
+    const uint32_t m = (1u << tbits) - 1u;
+    const uint32_t x = ((uint32_t)i & m) << tshift, y = (((uint32_t)(i >> tbits)) & m) << tshift, z = ((uint32_t)(i >> (2 * tbits)) & m) << tshift;
+    uint32_t node = 0, entry = 0;
+    bool done = false;
+    for (int sh = depth - 1; sh >= tshift; --sh) {
+        const uint2 nd = nodes[node];
+        const uint32_t oct = ((x >> sh) & 1u) | (((y >> sh) & 1u) << 1) | (((z >> sh) & 1u) << 2);
+        const uint32_t valid = nd.y & 0xFFu, bit = 1u << oct;
+        if (!(valid & bit)) { entry = 0x80000000u | (uint32_t)sh; done = true; break; }
+        node = nd.x + (uint32_t)__popc(valid & (bit - 1u));
+    }
+    table[i] = done ? entry : node;
 }
 
 // synthetic noise voxels (volume_gpu_generate_noise)

@@ -18,7 +18,8 @@ try:
 except ImportError:  # pragma: no cover
     pass
 
-_path = os.path.join(LIB_DIR, "libvolly_gpu.so")
+# VOLLY_GPU_LIB: another build of the same library (kernel A/B runs, profiles/ab_bench.py)
+_path = os.environ.get("VOLLY_GPU_LIB") or os.path.join(LIB_DIR, "libvolly_gpu.so")
 if not os.path.exists(_path):
     raise ImportError(f"{_path} is missing: the HIP extension must be built (make gpu / __graft_entry__.build()); "
                       "there is no CPU fallback")
