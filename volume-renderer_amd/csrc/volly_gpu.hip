@@ -113,12 +113,20 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
     d.nrx = (d.nbx + 3) / 4; d.nry = (d.nby + 3) / 4; d.nrz = (d.nbz + 3) / 4;
     const size_t nr = (size_t)d.nrx * d.nry * d.nrz;
     uint64_t *occ2 = nullptr;
-    if ((rc = dev_alloc(s, (void **)&occ2, nr * 8))) return rc;
+    if ((rc = dev_alloc(s, (void **)&occ2, nr * 8 + 8))) return rc;
+    uint32_t *counter = (uint32_t *)(occ2 + nr);
+    HIP_TRY(hipMemset(counter, 0, 8));
     hipLaunchKernelGGL(vk::build_occupancy2, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, 0, occ, d.nbx, d.nby, d.nbz, d.nrx,
-                       d.nry, d.nrz, occ2);
+                       d.nry, d.nrz, occ2, counter);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+    uint32_t nonempty = 0;
+    HIP_TRY(hipMemcpy(&nonempty, counter, 4, hipMemcpyDeviceToHost));
     d.occ2 = occ2;
+    // The region level pays when most 16^3 regions are empty (surface scenes); in a noise
+    // volume every region holds voxels and it is pure overhead.  VOLLY_USE_REGIONS=0/1 overrides.
+    d.use_regions = (uint64_t)nonempty * 2 <= (uint64_t)nr;
+    if (const char *e = std::getenv("VOLLY_USE_REGIONS")) d.use_regions = std::atoi(e) != 0;
     *out = d;
     return VOLLY_OK;
 }

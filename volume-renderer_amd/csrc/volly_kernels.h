@@ -71,6 +71,7 @@ struct DenseDev {
     int sx, sy, sz;
     int nbx, nby, nbz;              // bricks per axis
     int nrx, nry, nrz;              // 16^3 regions per axis
+    int use_regions;                // consult occ2 (set at upload when most regions are empty; useless for noise)
     float fsx, fsy, fsz;
     uint32_t cap;                   // iteration cap 4*(sx+sy+sz)+8 (the reference has none, main.cpp:121)
 };
@@ -264,47 +265,65 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
 #if VK_OCC_LEVELS == 2
     uint32_t last_region = 0xFFFFFFFFu;
     uint32_t r_lo = 0, r_hi = 0;
+    uint32_t r_any = 0;                                  // the current region holds at least one voxel
 #endif
-    for (;;) {
+    uint32_t live = 1;
+    // A lane samples once per loop iteration from the first one until it leaves the loop, so
+    // its step count is the iteration number at which it leaves: no per-lane counter, and the
+    // iteration cap is a wave-uniform test.  Lane state changes only inside the rare blocks.
+    for (uint32_t iter = 0;; ++iter) {
         float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
         int x = (int)px, y = (int)py, z = (int)pz;       // truncation toward zero, saturating
         uint32_t c = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
-        if (h.steps >= g.cap) break;
+        if (iter >= g.cap) { h.steps = iter; break; }    // uniform
 #if VK_OCC_LEVELS == 2
         uint32_t region = c & 0xFF0FC3F0u;
         if (region != last_region) {
             bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
-            if (!inside) break;
-            uint64_t bits = g.occ2[(uint32_t)(x >> 4) + (uint32_t)g.nrx * ((uint32_t)(y >> 4) + (uint32_t)g.nry * (uint32_t)(z >> 4))];
-            r_lo = (uint32_t)bits;
-            r_hi = (uint32_t)(bits >> 32);
-            last_region = region;
+            if (inside) {
+                uint64_t bits = ~0ull;                   // without the region level every brick is looked at
+                if (g.use_regions) bits = g.occ2[(uint32_t)(x >> 4) + (uint32_t)g.nrx * ((uint32_t)(y >> 4) + (uint32_t)g.nry * (uint32_t)(z >> 4))];
+                r_lo = (uint32_t)bits;
+                r_hi = (uint32_t)(bits >> 32);
+                r_any = (r_lo | r_hi) != 0u;
+                last_region = region;
+            } else {                                     // left the grid: main.cpp:126-135
+                r_any = 0;
+                live = 0;
+                h.steps = iter;
+            }
         }
-        ++h.steps;
-        if (test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {          // the brick holds voxels
+        if (r_any) {
+            if (!g.use_regions || test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {      // the brick holds voxels
 #else
         {
+            {
 #endif
-            uint32_t brick = c & 0xFFCFF3FCu;
-            if (brick != last_brick) {
+                uint32_t brick = c & 0xFFCFF3FCu;
+                bool inside = true;
+                if (brick != last_brick) {
 #if VK_OCC_LEVELS != 2
-                bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
-                if (!inside) break;
+                    inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
 #endif
-                uint64_t bits = g.occ[(uint32_t)(x >> 2) + (uint32_t)g.nbx * ((uint32_t)(y >> 2) + (uint32_t)g.nby * (uint32_t)(z >> 2))];
-                w_lo = (uint32_t)bits;
-                w_hi = (uint32_t)(bits >> 32);
-                last_brick = brick;
-            }
-#if VK_OCC_LEVELS != 2
-            ++h.steps;
-#endif
-            if (test_word(w_lo, w_hi, gather_bits(c & 0x00300C03u))) {
-                h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
-                h.payload = h.index;
-                break;
+                    if (inside) {
+                        uint64_t bits = g.occ[(uint32_t)(x >> 2) + (uint32_t)g.nbx * ((uint32_t)(y >> 2) + (uint32_t)g.nby * (uint32_t)(z >> 2))];
+                        w_lo = (uint32_t)bits;
+                        w_hi = (uint32_t)(bits >> 32);
+                        last_brick = brick;
+                    } else {
+                        live = 0;
+                        h.steps = iter;
+                    }
+                }
+                if (inside && test_word(w_lo, w_hi, gather_bits(c & 0x00300C03u))) {   // main.cpp:139-142
+                    live = 0;
+                    h.steps = iter + 1;
+                    h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
+                    h.payload = h.index;
+                }
             }
         }
+        if (!live) break;
         advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
     }
     return h;
@@ -583,7 +602,7 @@ __global__ void __launch_bounds__(256) build_occupancy(const uint2 *vox, int sx,
 
 // second occupancy level: one word per 4x4x4 bricks, bit set iff the brick holds a voxel
 __global__ void __launch_bounds__(256) build_occupancy2(const uint64_t *occ, int nbx, int nby, int nbz, int nrx, int nry, int nrz,
-                                                        uint64_t *occ2)
+                                                        uint64_t *occ2, uint32_t *nonempty_regions)
 {
     const size_t rg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nr = (size_t)nrx * nry * nrz;
@@ -595,6 +614,7 @@ __global__ void __launch_bounds__(256) build_occupancy2(const uint64_t *occ, int
         if (bx < nbx && by < nby && bz < nbz && occ[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * (size_t)bz)]) bits |= 1ull << k;
     }
     occ2[rg] = bits;
+    if (bits) atomicAdd(nonempty_regions, 1u);
 }
 
 // Upper octree levels as a direct-index table: entry (tx,ty,tz) describes the octree cell
