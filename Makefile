@@ -25,7 +25,7 @@ gpu: $(LIBDIR)/libvolly_gpu.so
 host: $(LIBDIR)/libvolly_host.so
 oracle: oracle/libvolly_oracle.so
 
-$(LIBDIR)/libvolly_gpu.so: $(PKG)/csrc/volly_gpu.hip $(PKG)/csrc/volly_kernels.h include/volly_gpu.h
+$(LIBDIR)/libvolly_gpu.so: $(PKG)/csrc/volly_gpu.hip $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_refill.h include/volly_gpu.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(FPFLAGS) -Iinclude \
 	    -o $@ $(PKG)/csrc/volly_gpu.hip

@@ -151,7 +151,8 @@ int volly_gpu_kernel_time(volly_gpu_scene *scene, double *ms_total, int *launche
 int volly_gpu_read_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count, void *out);
 
 /* Scene facts: 0 sx, 1 sy, 2 sz, 3 is_svo, 4 has_low, 5 low sx, 6 device,
- * 7 device bytes held (MiB). */
+ * 7 device bytes held (MiB), 8 frame kernel (0 tile per wavefront, 1 ray refill),
+ * 9 target grid uses the 16^3 region level. */
 int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
 
 void        volly_gpu_free(volly_gpu_scene *scene);

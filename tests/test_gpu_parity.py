@@ -183,6 +183,7 @@ def test_noise_scene_matches_host_hash(vra, ora):
     render of the generated scene equals the oracle on a host rebuild of it."""
     res, seed, thr = 64, 3, 1 << 25
     gpu = vra.GpuScene.noise(res, seed, thr)
+    assert gpu.info(8) == 0 and gpu.info(9) == 0      # every region holds voxels: the region level is switched off
     dev = gpu.read_voxels(0, res ** 3).reshape(res, res, res, 8)
     z, y, x = np.meshgrid(np.arange(res, dtype=np.uint32), np.arange(res, dtype=np.uint32),
                           np.arange(res, dtype=np.uint32), indexing="ij")
@@ -277,3 +278,32 @@ def test_reference_style_state_example(vra, ora, tmp_path):
         want = ora.render_frame(f, low=low, target=tgt)["rgba8"].view(np.uint8).reshape(300, 400, 4)
         assert want[..., 0].min() == 255
         assert np.array_equal(got, want[..., 1:4])
+
+
+def test_ray_refill_kernel(vra, ora, teapot64, sphere64, monkeypatch):
+    """The ray-refill frame kernel (opt-in, VOLLY_REFILL=1), on scenes where it meets every
+    case the tile kernel meets: beam and naive
+    frames, odd sizes, sub-rectangles, a batch, degenerate rays.  Same planes, bit for bit."""
+    monkeypatch.setenv("VOLLY_REFILL", "1")
+    for scene in (teapot64, sphere64):
+        hi, lo = _sizes(scene)
+        gpu = vra.GpuScene.upload_dense(scene.target, scene.low)
+        assert gpu.info(8) == 1
+        frames = list(vra.orbit_frames(range(0, 16, 5), 16, hi, lo, 150, 77, radius=0.9))
+        frames += list(vra.orbit_frames((3,), 16, hi, lo, 150, 77, radius=0.6, naive=True))
+        got = gpu.render(frames)
+        for i, f in enumerate(frames):
+            assert_planes_equal({k: v[i] for k, v in got.items()}, _oracle(ora, f, scene, "dense"), f"refill frame {i}")
+        sub = frames[1].copy()
+        sub.x0, sub.y0, sub.tile_w, sub.tile_h = 33, 9, 70, 41
+        assert_planes_equal({k: v[0] for k, v in gpu.render(sub).items()}, _oracle(ora, sub, scene, "dense"), "refill sub")
+        for row0, org in (((1, 0, 0), (-5, 32.5, 32.5)), ((0, 0, 0), (10, 10, 10)), ((1, 0, 0), (-5, -2.0, 32.5)),
+                          ((1, 1, 1), (-1, -1, -1))):
+            f = _manual_frame(vra, 16, 8, row0, (0, 0.25, 0), (0, 0, 0.25), org)
+            assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, _oracle(ora, f, scene, "dense"),
+                                f"refill degenerate {row0} {org}")
+        gpu.close()
+    monkeypatch.setenv("VOLLY_REFILL", "0")
+    gpu = vra.GpuScene.upload_dense(teapot64.target, teapot64.low)
+    assert gpu.info(8) == 0
+    gpu.close()

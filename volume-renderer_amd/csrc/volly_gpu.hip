@@ -1,6 +1,7 @@
 // volly_gpu.hip -- C-ABI of the MI355X traversal path (include/volly_gpu.h).
 // Built for gfx950 only, with -ffp-contract=off (see volly_kernels.h).
 #include "volly_kernels.h"
+#include "volly_refill.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -51,6 +52,7 @@ constexpr int kFrameChunk = 32;     // frames per launch (bounds the checkpoint 
 struct volly_gpu_scene {
     int device = 0;
     bool is_svo = false, has_low = false;
+    bool refill = false;            // incoherent dense scene: use the ray-refill frame kernel
     vk::DenseDev target{}, low{};
     vk::SvoDev svo{};
     // owned device allocations
@@ -123,9 +125,10 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
     uint32_t nonempty = 0;
     HIP_TRY(hipMemcpy(&nonempty, counter, 4, hipMemcpyDeviceToHost));
     d.occ2 = occ2;
-    // The region level pays when most 16^3 regions are empty (surface scenes); in a noise
-    // volume every region holds voxels and it is pure overhead.  VOLLY_USE_REGIONS=0/1 overrides.
-    d.use_regions = (uint64_t)nonempty * 2 <= (uint64_t)nr;
+    // The region level pays when a fair share of the 16^3 regions is empty (surface scenes:
+    // 20-55 % of the regions hold voxels in the bundled meshes, +9 % Mrays/s); in a noise
+    // volume every region holds voxels and it is pure overhead (-7 %).  VOLLY_USE_REGIONS=0/1 overrides.
+    d.use_regions = (uint64_t)nonempty * 10 <= (uint64_t)nr * 9;
     if (const char *e = std::getenv("VOLLY_USE_REGIONS")) d.use_regions = std::atoi(e) != 0;
     *out = d;
     return VOLLY_OK;
@@ -154,6 +157,23 @@ int new_scene(int device, volly_gpu_scene **out)
     s->device = device;
     *out = s;
     return VOLLY_OK;
+}
+
+bool host_grid_is_regular(const vk::DenseDev &g)
+{
+    return ((g.sx | g.sy | g.sz) & 15) == 0 && g.sx <= 1024 && g.sy <= 1024 && g.sz <= 1024;
+}
+
+// The ray-refill frame kernel (volly_refill.h) is an experiment kept for measurement: on the
+// noise volume it was built for it needs 25 % fewer VALU instructions than the tile kernel but
+// issues 8x the L2 requests (lanes no longer share brick lines) and runs its per-ray set-up
+// at 25 % lane packing: 5.3 ms against 4.6 ms.  Off unless VOLLY_REFILL=1.
+void choose_frame_kernel(volly_gpu_scene *s)
+{
+    bool ok = !s->is_svo && host_grid_is_regular(s->target) && (!s->has_low || host_grid_is_regular(s->low));
+    bool want = false;
+    if (const char *e = std::getenv("VOLLY_REFILL")) want = ok && std::atoi(e) != 0;
+    s->refill = want;
 }
 
 int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, int n_frames)
@@ -209,7 +229,12 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         HIP_TRY(hipEventRecord(e0, stream));
     }
     dim3 grid((unsigned)((tw + vk::kBlockW - 1) / vk::kBlockW), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
-    if (s->is_svo)
+    if (s->refill) {
+        const unsigned tiles = (unsigned)groups * (unsigned)((th + vk::kTile - 1) / vk::kTile);
+        const unsigned waves = (tiles + vk::kRaysPerWave / 64 - 1) / (vk::kRaysPerWave / 64);
+        hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
+                           s->low, s->d_frames, s->d_ckpt, o);
+    } else if (s->is_svo)
         hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
                            s->d_ckpt, o);
     else
@@ -248,6 +273,7 @@ int volume_gpu_upload(int device, const volly_dense_desc *target, const volly_de
         s->has_low = true;
     }
     if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
+    choose_frame_kernel(s);
     *out = s;
     return VOLLY_OK;
 }
@@ -356,6 +382,7 @@ int volume_gpu_generate_noise(int device, int32_t res, uint32_t seed, uint32_t t
     if (!rc) rc = make_dense(s, lr, lr, lr, nullptr, vox_lo, &s->low);
     if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
     s->has_low = true;
+    choose_frame_kernel(s);
     *out = s;
     return VOLLY_OK;
 }
@@ -455,6 +482,8 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 5: return s->has_low ? s->low.sx : 0;
     case 6: return s->device;
     case 7: return (int64_t)(s->bytes >> 20);
+    case 8: return s->refill;
+    case 9: return s->is_svo ? 0 : s->target.use_regions;
     default: return -1;
     }
 }

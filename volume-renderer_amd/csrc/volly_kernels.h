@@ -252,6 +252,7 @@ __device__ __forceinline__ bool test_word(uint32_t w_lo, uint32_t w_hi, uint32_t
 //     last non-empty brick in registers: steps through empty bricks read no memory, and a
 //     wavefront of neighbouring rays reloads only when it enters a new region or a brick with
 //     content -- the dependent-load latency that otherwise paces the loop.
+template <bool REGIONS>
 __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
     Hit h;
@@ -262,11 +263,9 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
     if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
     uint32_t last_brick = 0xFFFFFFFFu;                   // no brick yet: valid keys have bits 0-1 clear
     uint32_t w_lo = 0, w_hi = 0;
-#if VK_OCC_LEVELS == 2
     uint32_t last_region = 0xFFFFFFFFu;
     uint32_t r_lo = 0, r_hi = 0;
     uint32_t r_any = 0;                                  // the current region holds at least one voxel
-#endif
     uint32_t live = 1;
     // A lane samples once per loop iteration from the first one until it leaves the loop, so
     // its step count is the iteration number at which it leaves: no per-lane counter, and the
@@ -276,13 +275,11 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
         int x = (int)px, y = (int)py, z = (int)pz;       // truncation toward zero, saturating
         uint32_t c = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
         if (iter >= g.cap) { h.steps = iter; break; }    // uniform
-#if VK_OCC_LEVELS == 2
         uint32_t region = c & 0xFF0FC3F0u;
-        if (region != last_region) {
+        if (REGIONS && region != last_region) {
             bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
             if (inside) {
-                uint64_t bits = ~0ull;                   // without the region level every brick is looked at
-                if (g.use_regions) bits = g.occ2[(uint32_t)(x >> 4) + (uint32_t)g.nrx * ((uint32_t)(y >> 4) + (uint32_t)g.nry * (uint32_t)(z >> 4))];
+                uint64_t bits = g.occ2[(uint32_t)(x >> 4) + (uint32_t)g.nrx * ((uint32_t)(y >> 4) + (uint32_t)g.nry * (uint32_t)(z >> 4))];
                 r_lo = (uint32_t)bits;
                 r_hi = (uint32_t)(bits >> 32);
                 r_any = (r_lo | r_hi) != 0u;
@@ -293,18 +290,12 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
                 h.steps = iter;
             }
         }
-        if (r_any) {
-            if (!g.use_regions || test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {      // the brick holds voxels
-#else
-        {
-            {
-#endif
+        if (!REGIONS || r_any) {
+            if (!REGIONS || test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {      // the brick holds voxels
                 uint32_t brick = c & 0xFFCFF3FCu;
                 bool inside = true;
                 if (brick != last_brick) {
-#if VK_OCC_LEVELS != 2
-                    inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
-#endif
+                    if (!REGIONS) inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
                     if (inside) {
                         uint64_t bits = g.occ[(uint32_t)(x >> 2) + (uint32_t)g.nbx * ((uint32_t)(y >> 2) + (uint32_t)g.nby * (uint32_t)(z >> 2))];
                         w_lo = (uint32_t)bits;
@@ -333,7 +324,11 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
 {
 #if VK_FAST_DDA && !VK_AOS_SAMPLE
     // one path per wavefront, so the two loops never run interleaved in a wave
-    if (grid_is_regular(g) && __all(ray_is_regular(r))) return trace_dense_regular(g, r, ox, oy, oz);
+    if (grid_is_regular(g) && __all(ray_is_regular(r))) {
+        // the 16^3 region level is chosen per grid at upload (DenseDev::use_regions)
+        if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regular<true>(g, r, ox, oy, oz);
+        return trace_dense_regular<false>(g, r, ox, oy, oz);
+    }
 #endif
     return trace_dense_checked(g, r, ox, oy, oz);
 }
