@@ -50,6 +50,9 @@ def parse():
                     help="one frame per step split into row bands over the ranks + gather to rank 0 (config 4)")
     ap.add_argument("--mode", choices=["beam", "naive"], default="beam",
                     help="beam = raycast_beamOpt (the reference's live path); naive = traversal from the camera")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend; gloo + --force-device rehearses the N>1 paths on a one-GPU box")
+    ap.add_argument("--force-device", type=int, default=None, help="use this GPU on every rank (rehearsal only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the workload timed on the CPU oracle (0 = auto)")
     args = ap.parse_args()
@@ -69,13 +72,19 @@ def main():
     from __graft_entry__ import load_package
     vra = load_package()
 
+    if args.force_device is not None:
+        local_rank = args.force_device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective operands live
 
     # ---- scene: host voxelization + octree build (or device-side noise), one upload to HBM ----
     t0 = time.time()
@@ -126,7 +135,7 @@ def main():
     def run(frames):
         gpu.render_device(frames, ptrs, stream=stream.cuda_stream)
         if split:      # frame assembly on rank 0: the one collective of the path (RCCL gather over xGMI)
-            assembled[0] = vra.shard.gather_bands(planes["rgba8"][0], H, W, rank, world, dist, dst=0)
+            assembled[0] = vra.shard.gather_bands(planes["rgba8"][0].to(coll_dev), H, W, rank, world, dist, dst=0)
 
     for s in range(args.warmup):
         run(all_frames[s])
@@ -148,7 +157,7 @@ def main():
     gpu.set_profiling(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -165,6 +174,15 @@ def main():
         h = int((planes["hit_index"] != -1).sum().item())
         sum_lo += lo; sum_hi += hi; hits += h
         alg_bytes += 8 * (lo + hi) + 8 * h + 20 * rays_per_launch
+
+    assembled_ok = None
+    if split and rank == 0:     # the assembled frame equals the frame one GPU renders alone
+        last = args.warmup + args.steps - 1
+        full = vra.orbit_frames([last % ORBIT_VIEWS], ORBIT_VIEWS, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
+        alone = torch.empty((1, H, W), dtype=torch.int32, device=dev)
+        gpu.render_device(full, {"rgba8": alone.data_ptr()}, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        assembled_ok = bool(torch.equal(assembled[0].to(dev), alone[0]))
 
     rays_per_step = (H * W) if split else (B * H * W * world)       # whole job, all ranks
     mrays = rays_per_step * args.steps / elapsed / 1e6
@@ -185,6 +203,8 @@ def main():
                    "hit_fraction": round(hits / (rays_per_launch * args.steps), 4),
                    "scene_setup_s": round(setup_s, 2), "scene_device_mib": gpu.info(7)},
     }
+    if assembled_ok is not None:
+        out["config"]["assembled_frame_equals_single_gpu_frame"] = assembled_ok
     if launches:
         avg_ms = kern_ms / launches
         alg_per_launch = alg_bytes / launches

@@ -210,7 +210,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     }
     HIP_TRY(hipMemcpyAsync(s->d_frames, frames, sizeof(volly_frame_desc) * (size_t)n, hipMemcpyHostToDevice, stream));
 
-    hipLaunchKernelGGL(vk::direction_checkpoints, dim3((unsigned)((th + 63) / 64), (unsigned)n), dim3(64), 0, stream,
+    hipLaunchKernelGGL(vk::direction_checkpoints, dim3((unsigned)((th + 63) / 64), (unsigned)n, 6), dim3(64), 0, stream,
                        s->d_frames, n, s->d_ckpt);
     HIP_TRY(hipGetLastError());
 

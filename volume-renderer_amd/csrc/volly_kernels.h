@@ -438,42 +438,34 @@ __device__ __forceinline__ uint32_t shade(uint2 vox)
 }
 
 // ---- pre-pass: serial ray-direction sums (main.cpp:254-255,282-286) -----------
-// One thread per (frame, row of the sub-rectangle).  Walks the row's running
-// sums and stores them every kTile pixels, for both the target and the low grid.
-// ckpt layout: [frame][column group][row][6 floats] (hi xyz, lo xyz).
+// One thread per (frame, row of the sub-rectangle, component): the six components (target
+// xyz, low xyz) are independent chains of dependent adds, so each gets its own thread.
+// A thread walks its chain -- y adds down to its row, then along the row -- and stores the
+// running sum every kTile pixels.  ckpt layout: [frame][column group][row][6 floats].
 __global__ void __launch_bounds__(64)
 direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames, float *__restrict__ ckpt)
 {
     const int f = blockIdx.y;
     if (f >= n_frames) return;
-    const volly_frame_desc fd = frames[f];                // private copy: the loops below must not re-read it
+    const int comp = blockIdx.z;                          // 0..2 target xyz, 3..5 low xyz
+    const volly_frame_desc &fd = frames[f];
+    const int tile_w = fd.tile_w, tile_h = fd.tile_h, x0 = fd.x0;
     const int yrel = blockIdx.x * blockDim.x + threadIdx.x;
-    if (yrel >= fd.tile_h) return;
+    if (yrel >= tile_h) return;
     const int y = fd.y0 + yrel;
-    float hx = fd.row0_hi[0], hy = fd.row0_hi[1], hz = fd.row0_hi[2];
-    float lx = fd.row0_lo[0], ly = fd.row0_lo[1], lz = fd.row0_lo[2];
-    const float yhx = fd.ydiff_hi[0], yhy = fd.ydiff_hi[1], yhz = fd.ydiff_hi[2];
-    const float ylx = fd.ydiff_lo[0], yly = fd.ydiff_lo[1], ylz = fd.ydiff_lo[2];
-    for (int i = 0; i < y; ++i) {                         // main.cpp:285-286
-        hx = hx + yhx; hy = hy + yhy; hz = hz + yhz;
-        lx = lx + ylx; ly = ly + yly; lz = lz + ylz;
-    }
-    const float xhx = fd.xdiff_hi[0], xhy = fd.xdiff_hi[1], xhz = fd.xdiff_hi[2];
-    const float xlx = fd.xdiff_lo[0], xly = fd.xdiff_lo[1], xlz = fd.xdiff_lo[2];
-    const int groups = (fd.tile_w + kTile - 1) / kTile;
-    const size_t frame_base = (size_t)f * (size_t)groups * (size_t)fd.tile_h;
-    for (int x = 0; x < fd.x0; ++x) {                     // main.cpp:282-283, columns left of the sub-rectangle
-        hx = hx + xhx; hy = hy + xhy; hz = hz + xhz;
-        lx = lx + xlx; ly = ly + xly; lz = lz + xlz;
-    }
+    const int lo = comp >= 3, k = comp - 3 * lo;
+    float v = lo ? fd.row0_lo[k] : fd.row0_hi[k];
+    const float dy = lo ? fd.ydiff_lo[k] : fd.ydiff_hi[k];
+    const float dx = lo ? fd.xdiff_lo[k] : fd.xdiff_hi[k];
+    for (int i = 0; i < y; ++i) v = v + dy;               // main.cpp:285-286
+    for (int x = 0; x < x0; ++x) v = v + dx;              // main.cpp:282-283, columns left of the sub-rectangle
+    const int groups = (tile_w + kTile - 1) / kTile;
+    float *o = ckpt + ((size_t)f * (size_t)groups * (size_t)tile_h + (size_t)yrel) * 6 + comp;
+    const size_t stride = (size_t)tile_h * 6;
     for (int g = 0; g < groups; ++g) {
-        float *o = ckpt + (frame_base + (size_t)g * (size_t)fd.tile_h + (size_t)yrel) * 6;
-        o[0] = hx; o[1] = hy; o[2] = hz; o[3] = lx; o[4] = ly; o[5] = lz;
+        o[(size_t)g * stride] = v;
         #pragma unroll
-        for (int i = 0; i < kTile; ++i) {
-            hx = hx + xhx; hy = hy + xhy; hz = hz + xhz;
-            lx = lx + xlx; ly = ly + xly; lz = lz + xlz;
-        }
+        for (int i = 0; i < kTile; ++i) v = v + dx;
     }
 }
 
