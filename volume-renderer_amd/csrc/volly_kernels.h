@@ -441,7 +441,8 @@ __device__ __forceinline__ uint32_t shade(uint2 vox)
 // One thread per (frame, row of the sub-rectangle, component): the six components (target
 // xyz, low xyz) are independent chains of dependent adds, so each gets its own thread.
 // A thread walks its chain -- y adds down to its row, then along the row -- and stores the
-// running sum every kTile pixels.  ckpt layout: [frame][column group][row][6 floats].
+// running sum every kTile pixels.  ckpt layout: [frame][column group][component][row], so
+// the 64 rows of a workgroup store 256 contiguous bytes.
 __global__ void __launch_bounds__(64)
 direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames, float *__restrict__ ckpt)
 {
@@ -457,10 +458,15 @@ direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames,
     float v = lo ? fd.row0_lo[k] : fd.row0_hi[k];
     const float dy = lo ? fd.ydiff_lo[k] : fd.ydiff_hi[k];
     const float dx = lo ? fd.xdiff_lo[k] : fd.xdiff_hi[k];
-    for (int i = 0; i < y; ++i) v = v + dy;               // main.cpp:285-286
+    int i = 0;
+    for (; i + 8 <= y; i += 8) {                          // main.cpp:285-286
+        #pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) v = v + dy;
+    }
+    for (; i < y; ++i) v = v + dy;
     for (int x = 0; x < x0; ++x) v = v + dx;              // main.cpp:282-283, columns left of the sub-rectangle
     const int groups = (tile_w + kTile - 1) / kTile;
-    float *o = ckpt + ((size_t)f * (size_t)groups * (size_t)tile_h + (size_t)yrel) * 6 + comp;
+    float *o = ckpt + ((size_t)f * (size_t)groups * 6 + (size_t)comp) * (size_t)tile_h + (size_t)yrel;
     const size_t stride = (size_t)tile_h * 6;
     for (int g = 0; g < groups; ++g) {
         o[(size_t)g * stride] = v;
@@ -514,8 +520,9 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
 
     if (active) {
         const int groups = (fd.tile_w + kTile - 1) / kTile;
-        const float *c = ckpt + (((size_t)f * (size_t)groups + (size_t)(xrel / kTile)) * (size_t)fd.tile_h + (size_t)yrel) * 6;
-        float hx = c[0], hy = c[1], hz = c[2], lx = c[3], ly = c[4], lz = c[5];
+        const size_t cs = (size_t)fd.tile_h;
+        const float *c = ckpt + ((size_t)f * (size_t)groups + (size_t)(xrel / kTile)) * 6 * cs + (size_t)yrel;
+        float hx = c[0], hy = c[cs], hz = c[2 * cs], lx = c[3 * cs], ly = c[4 * cs], lz = c[5 * cs];
         const int extra = xrel % kTile;
         for (int i = 0; i < extra; ++i) {                 // main.cpp:282-283
             hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];

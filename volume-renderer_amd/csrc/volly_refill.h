@@ -120,8 +120,9 @@ render_frames_refill(DenseDev target, DenseDev low, const volly_frame_desc *__re
                     const int yrel = (int)(tile / (uint32_t)tiles_x) * kTile + (int)(in_tile >> 3);
                     if (xrel < fd.tile_w && yrel < fd.tile_h) {
                         pix = (uint32_t)yrel * (uint32_t)fd.tile_w + (uint32_t)xrel;
-                        const float *c = ckpt + (((size_t)f * (size_t)groups + (size_t)(xrel / kTile)) * (size_t)fd.tile_h + (size_t)yrel) * 6;
-                        float hx = c[0], hy = c[1], hz = c[2], lx = c[3], ly = c[4], lz = c[5];
+                        const size_t cs = (size_t)fd.tile_h;
+                        const float *c = ckpt + ((size_t)f * (size_t)groups + (size_t)(xrel / kTile)) * 6 * cs + (size_t)yrel;
+                        float hx = c[0], hy = c[cs], hz = c[2 * cs], lx = c[3 * cs], ly = c[4 * cs], lz = c[5 * cs];
                         const int extra = xrel % kTile;
                         for (int i = 0; i < extra; ++i) { // main.cpp:282-283
                             hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];
