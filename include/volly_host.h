@@ -40,6 +40,14 @@ int  volly_host_scene_svo(const volly_host_scene *s, volly_svo_desc *out);
 int64_t volly_host_scene_lod_count(const volly_host_scene *s, int32_t lod);
 void volly_host_scene_free(volly_host_scene *s);
 
+/* On-disk scene cache.  The reference re-voxelizes every mesh at every start
+ * (main.cpp:369-387) and its .vol readers are dead (volume.cpp:135-275); this stores what
+ * volly_host_scene_from_mesh produced -- low grid, dense target and/or octree -- as one
+ * little-endian blob with a checksum.  load returns NULL (and an error) for a missing,
+ * truncated, corrupted or foreign file. */
+int volly_host_scene_save(const volly_host_scene *s, const char *path);
+volly_host_scene *volly_host_scene_load(const char *path);
+
 /* The reference's default four-grid set (main.h:79: 16/32/128/256); which = 0..3 = arr[] */
 typedef struct volly_host_lod_set volly_host_lod_set;
 volly_host_lod_set *volly_host_lod_set_load(const char *path, int32_t sLowR, int32_t lowR, int32_t medR, int32_t highR);

@@ -245,3 +245,33 @@ def test_look_at_is_a_rotation(vra):
     m = view.reshape(4, 4).T[:3, :3].astype(np.float64)
     assert np.allclose(m @ m.T, np.eye(3), atol=1e-5)
     assert np.allclose(np.linalg.norm(pos - 0.5), np.sqrt(1.2 ** 2 + (pos[2] - 0.5) ** 2), atol=1e-5)
+
+
+def test_scene_cache_round_trip_and_rejection(vra, tmp_path):
+    """On-disk scene cache (SURVEY 8f-3): what comes back is byte for byte what was saved;
+    missing, foreign, truncated and corrupted files are refused."""
+    scene = vra.HostScene.from_mesh(os.path.join(ASSETS, "teapot.off"), 64)
+    path = tmp_path / "teapot64.volly"
+    scene.save(path)
+    back = vra.HostScene.load(path)
+    assert np.array_equal(vra.host.dense_view(back.target), vra.host.dense_view(scene.target))
+    assert np.array_equal(vra.host.dense_view(back.low), vra.host.dense_view(scene.low))
+    n0, l0 = scene.svo_arrays(); n1, l1 = back.svo_arrays()
+    assert np.array_equal(n0, n1) and np.array_equal(l0, l1)
+    assert (back.svo.depth, back.svo.res) == (scene.svo.depth, scene.svo.res)
+    assert back.lod_count(0) == -1                       # the voxel map itself is not cached
+    # octree-only scene
+    svo_only = vra.HostScene.from_mesh(os.path.join(ASSETS, "icosahedron.off"), 32, dense=False, svo=True)
+    p2 = tmp_path / "ico.volly"
+    svo_only.save(p2)
+    b2 = vra.HostScene.load(p2)
+    assert b2.target is None and b2.svo.n_leaves == svo_only.svo.n_leaves
+    raw = path.read_bytes()
+    for name, data in (("trunc", raw[:len(raw) // 2]), ("flip", raw[:200] + bytes([raw[200] ^ 1]) + raw[201:]),
+                       ("extra", raw + b"x"), ("foreign", b"OFF\n1 2 3\n")):
+        bad = tmp_path / name
+        bad.write_bytes(data)
+        with pytest.raises(RuntimeError):
+            vra.HostScene.load(bad)
+    with pytest.raises(RuntimeError):
+        vra.HostScene.load(tmp_path / "nope.volly")

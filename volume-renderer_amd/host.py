@@ -25,6 +25,8 @@ _sig = {
     "volly_host_scene_svo": (C.c_int, [_vp, C.POINTER(SvoDesc)]),
     "volly_host_scene_lod_count": (_i64, [_vp, _i32]),
     "volly_host_scene_free": (None, [_vp]),
+    "volly_host_scene_save": (C.c_int, [_vp, C.c_char_p]),
+    "volly_host_scene_load": (_vp, [C.c_char_p]),
     "volly_host_lod_set_load": (_vp, [C.c_char_p, _i32, _i32, _i32, _i32]),
     "volly_host_lod_set_grid": (C.c_int, [_vp, _i32, C.POINTER(DenseDesc)]),
     "volly_host_lod_set_free": (None, [_vp]),
@@ -92,6 +94,15 @@ class HostScene:
         l = dense_desc(low) if low is not None else None
         return cls(lib.volly_host_scene_from_dense(C.byref(t), C.byref(l) if l is not None else None,
                                                    SCENE_DENSE | (SCENE_SVO if svo else 0)))
+
+    def save(self, path):
+        """Write the scene cache (low grid, dense target and/or octree) to `path`."""
+        if lib.volly_host_scene_save(self._h, os.fsencode(path)) != VOLLY_OK:
+            raise RuntimeError("scene cache: " + _err())
+
+    @classmethod
+    def load(cls, path):
+        return cls(lib.volly_host_scene_load(os.fsencode(path)))
 
     def _get(self, fn, desc):
         rc = fn(self._h, C.byref(desc))

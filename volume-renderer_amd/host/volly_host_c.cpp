@@ -3,8 +3,10 @@
 #include "volly_scene.h"
 #include "tricube.h"
 
+#include <cstdio>
 #include <memory>
 #include <string>
+#include <vector>
 
 using namespace volly;
 
@@ -127,6 +129,112 @@ int64_t volly_host_scene_lod_count(const volly_host_scene *s, int32_t lod)
 }
 
 void volly_host_scene_free(volly_host_scene *s) { delete s; }
+
+// ---- scene cache ------------------------------------------------------------
+// layout: magic[8] | u32 version | u32 flags | i32 low[3] | i32 target[3] | u32 n_nodes | u32 n_leaves |
+//         i32 depth | i32 res | u64 fnv1a of the payload | payload (low, target, nodes, leaves)
+namespace {
+const char kMagic[8] = {'V', 'O', 'L', 'L', 'Y', 'S', 'C', '1'};
+struct CacheHeader {
+    char magic[8];
+    uint32_t version, flags;
+    int32_t low[3], target[3];
+    uint32_t n_nodes, n_leaves;
+    int32_t depth, res;
+    uint64_t checksum;
+};
+uint64_t fnv1a(uint64_t h, const void *p, size_t n)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001B3ull; }
+    return h;
+}
+struct File {
+    FILE *f;
+    explicit File(FILE *f_) : f(f_) {}
+    ~File() { if (f) std::fclose(f); }
+};
+} // namespace
+
+int volly_host_scene_save(const volly_host_scene *s, const char *path)
+{
+    g_err.clear();
+    if (!s || !path || !s->low) { g_err = "volly_host_scene_save: need a scene with a low grid and a path"; return VOLLY_E_ARG; }
+    CacheHeader h{};
+    std::memcpy(h.magic, kMagic, 8);
+    h.version = 1;
+    h.flags = (s->target ? VOLLY_SCENE_DENSE : 0) | (s->svo ? VOLLY_SCENE_SVO : 0);
+    h.low[0] = s->low->size.x; h.low[1] = s->low->size.y; h.low[2] = s->low->size.z;
+    if (s->target) { h.target[0] = s->target->size.x; h.target[1] = s->target->size.y; h.target[2] = s->target->size.z; }
+    if (s->svo) {
+        h.n_nodes = (uint32_t)s->svo->data.size(); h.n_leaves = (uint32_t)s->svo->leaves.size();
+        h.depth = s->svo->maxScale; h.res = s->svo->res;
+    }
+    struct Part { const void *p; size_t n; };
+    std::vector<Part> parts;
+    parts.push_back({s->low->data, s->low->count() * sizeof(Voxel)});
+    if (s->target) parts.push_back({s->target->data, s->target->count() * sizeof(Voxel)});
+    if (s->svo) {
+        parts.push_back({s->svo->data.data(), s->svo->data.size() * sizeof(volly_svo_node)});
+        parts.push_back({s->svo->leaves.data(), s->svo->leaves.size() * sizeof(Voxel)});
+    }
+    uint64_t sum = 0xCBF29CE484222325ull;
+    for (const Part &pt : parts) sum = fnv1a(sum, pt.p, pt.n);
+    h.checksum = sum;
+    File out(std::fopen(path, "wb"));
+    if (!out.f) { g_err = std::string("cannot write ") + path; return VOLLY_E_ARG; }
+    bool ok = std::fwrite(&h, sizeof h, 1, out.f) == 1;
+    for (const Part &pt : parts) ok = ok && (pt.n == 0 || std::fwrite(pt.p, 1, pt.n, out.f) == pt.n);
+    if (!ok) { g_err = std::string("short write to ") + path; return VOLLY_E_ARG; }
+    return VOLLY_OK;
+}
+
+volly_host_scene *volly_host_scene_load(const char *path)
+{
+    g_err.clear();
+    if (!path) { g_err = "volly_host_scene_load: null path"; return nullptr; }
+    File in(std::fopen(path, "rb"));
+    if (!in.f) { g_err = std::string("cannot open ") + path; return nullptr; }
+    CacheHeader h{};
+    if (std::fread(&h, sizeof h, 1, in.f) != 1 || std::memcmp(h.magic, kMagic, 8) != 0 || h.version != 1) {
+        g_err = std::string("not a volly scene cache: ") + path;
+        return nullptr;
+    }
+    auto bad_dim = [](const int32_t d[3]) { return d[0] < 1 || d[1] < 1 || d[2] < 1 || d[0] > 4096 || d[1] > 4096 || d[2] > 4096; };
+    if (bad_dim(h.low) || ((h.flags & VOLLY_SCENE_DENSE) && bad_dim(h.target)) ||
+        ((h.flags & VOLLY_SCENE_SVO) && (h.n_nodes < 1 || h.depth < 1 || h.depth > 13 || h.res < 1 || h.res > (1 << h.depth)))) {
+        g_err = std::string("implausible header in ") + path;
+        return nullptr;
+    }
+    auto s = std::make_unique<volly_host_scene>();
+    uint64_t sum = 0xCBF29CE484222325ull;
+    auto read = [&](void *p, size_t n) {
+        if (n && std::fread(p, 1, n, in.f) != n) return false;
+        sum = fnv1a(sum, p, n);
+        return true;
+    };
+    bool ok = true;
+    s->low = std::make_unique<VolumeStore<Voxel>>(ivec3(h.low[0], h.low[1], h.low[2]));
+    ok = ok && read((void *)s->low->data, s->low->count() * sizeof(Voxel));
+    if (ok && (h.flags & VOLLY_SCENE_DENSE)) {
+        s->target = std::make_unique<VolumeStore<Voxel>>(ivec3(h.target[0], h.target[1], h.target[2]));
+        ok = read((void *)s->target->data, s->target->count() * sizeof(Voxel));
+    }
+    if (ok && (h.flags & VOLLY_SCENE_SVO)) {
+        s->svo = std::make_unique<SparseVoxelOctree>();
+        s->svo->maxScale = h.depth; s->svo->res = h.res;
+        s->svo->data.resize(h.n_nodes);
+        s->svo->leaves.resize(h.n_leaves);
+        ok = read(s->svo->data.data(), (size_t)h.n_nodes * sizeof(volly_svo_node)) &&
+             read(s->svo->leaves.data(), (size_t)h.n_leaves * sizeof(Voxel));
+    }
+    if (ok && std::fgetc(in.f) != EOF) ok = false;                    // trailing bytes
+    if (!ok || sum != h.checksum) {
+        g_err = std::string("truncated or corrupted scene cache: ") + path;
+        return nullptr;
+    }
+    return s.release();
+}
 
 volly_host_lod_set *volly_host_lod_set_load(const char *path, int32_t sLowR, int32_t lowR, int32_t medR, int32_t highR)
 {

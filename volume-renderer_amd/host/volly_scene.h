@@ -120,6 +120,7 @@ public:
     int maxScale = 0;                    // svo.cpp:16
     int res = 0;
 
+    SparseVoxelOctree() = default;      // filled by the scene cache loader
     // from the LoD-0 entries of a voxel map (the reference signature, svo.h:38)
     SparseVoxelOctree(const VoxelMap *coords, int res);
     // from a dense grid (leaves = its non-empty voxels)
