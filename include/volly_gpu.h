@@ -37,6 +37,10 @@ extern "C" {
 /* frame flags */
 #define VOLLY_FRAME_BEAM   0    /* raycast_beamOpt, main.cpp:163-166,260 (the live path)      */
 #define VOLLY_FRAME_NAIVE  1    /* raycast_naiive_vec4 from camPos_Local, main.cpp:261        */
+#define VOLLY_FRAME_RAYTRACE 2  /* raytrace_naiive(3, camPos_Local, ...), main.cpp:170-194 and the
+                                   commented call site main.cpp:274-278: reflect / refract recursion
+                                   with raycast_naiive_vec4<true>.  Dense targets only.  rgba8 holds
+                                   the traced colour; the other planes describe the primary ray.     */
 
 typedef struct volly_gpu_scene volly_gpu_scene;   /* opaque, owns device memory */
 

@@ -221,6 +221,65 @@ void vo_raycast_svo(const float start[3], const float dir[3], const volly_svo_de
     report_miss(out, cur, steps, 0);
 }
 
+/* ------------------------------------- raytrace_naiive, main.cpp:170-194 --- */
+
+static float dot4(const float a[4], const float b[4])
+{
+    /* glm::dot(vec4): (x + y) + (z + w) of the products */
+    float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2], p3 = a[3] * b[3];
+    return (p0 + p1) + (p2 + p3);
+}
+
+void vo_raytrace(int iteration, const float start[3], const float direction[4], const volly_dense_desc *grid,
+                 float out[4], vo_report *primary)
+{
+    const float one_over_127 = 1.f / 127.f, one_over_255 = 1.f / 255.f;
+    vo_report rep;
+    vo_raycast_dense(start, direction, grid, 0, &rep);
+    if (primary) *primary = rep;
+    if (iteration <= 1 || !rep.found) {                       /* main.cpp:177 */
+        for (int c = 0; c < 4; ++c) out[c] = (float)rep.vox[c] * one_over_255;
+        return;
+    }
+    float norm[4];
+    for (int c = 0; c < 4; ++c) {                             /* main.cpp:179-180, unfused */
+        float p = (float)rep.vox[4 + c] * one_over_127;
+        norm[c] = p + -1.0f;
+    }
+    /* glm::reflect: I - N * dot(N, I) * 2 */
+    float d = dot4(norm, direction);
+    float reflect_dir[4], refract_dir[4];
+    for (int c = 0; c < 4; ++c) {
+        float nd = norm[c] * d;
+        float nd2 = nd * 2.f;
+        reflect_dir[c] = direction[c] - nd2;
+    }
+    /* glm::refract(I, N, eta = 2): k = 1 - eta*eta*(1 - d*d); k >= 0 ? eta*I - (eta*d + sqrt(k))*N : 0 */
+    {
+        const float eta = 2.f;
+        float dd = d * d;
+        float k = 1.f - (eta * eta) * (1.f - dd);
+        if (k >= 0.f) {
+            float f = eta * d + sqrtf(k);
+            for (int c = 0; c < 4; ++c) refract_dir[c] = eta * direction[c] - f * norm[c];
+        } else {
+            for (int c = 0; c < 4; ++c) refract_dir[c] = 0.f;
+        }
+    }
+    vo_report refr;
+    vo_raycast_dense(rep.pt_end, refract_dir, grid, 1, &refr);        /* main.cpp:185, solid */
+    float reflect_col[4], refract_col[4];
+    vo_raytrace(iteration - 1, rep.pt_end, reflect_dir, grid, reflect_col, 0);
+    vo_raytrace(iteration - 1, refr.pt_end, direction, grid, refract_col, 0);
+    const float amt_reflect = 0.35f, amt_refract = 0.00f, amt_diffuse = 0.65f;
+    for (int c = 0; c < 4; ++c) {                             /* main.cpp:193 */
+        float a = amt_reflect * reflect_col[c];
+        float b = amt_refract * refract_col[c];
+        float e = (amt_diffuse * (float)rep.vox[c]) * one_over_255;
+        out[c] = (a + b) + e;
+    }
+}
+
 /* ----------------------------------------------- beam, main.cpp:163-166 ---- */
 
 void vo_raycast_beam(const float start_lo[3], const float dir_hi[3], const float dir_lo[3],
@@ -296,14 +355,24 @@ static void render_row(const volly_frame_desc *f, int y, const float row_hi[3], 
 {
     float cx_hi[3] = { row_hi[0], row_hi[1], row_hi[2] };
     float cx_lo[3] = { row_lo[0], row_lo[1], row_lo[2] };
-    const int naive = (f->flags & VOLLY_FRAME_NAIVE) != 0;
+    const int raytrace = (f->flags & VOLLY_FRAME_RAYTRACE) != 0;
+    const int naive = raytrace || (f->flags & VOLLY_FRAME_NAIVE) != 0;
     for (int x = 0; x < f->x0 + f->tile_w; ++x) {
         if (x >= f->x0) {
             float dir_hi[3], dir_lo[3];
+            float traced[4] = { 0, 0, 0, 0 };
             vo_report lo, hi;
             normalize3_w0(cx_hi, dir_hi);
             memset(&lo, 0, sizeof lo);
-            if (naive) {
+            if (raytrace) {                               /* main.cpp:274-278 (commented call site) */
+                float inv_w;                              /* w of normalize(vec4(x,y,z,0)) = 0 * inversesqrt */
+                {
+                    float xx = cx_hi[0] * cx_hi[0], yy = cx_hi[1] * cx_hi[1], zz = cx_hi[2] * cx_hi[2];
+                    inv_w = 0.0f * (1.0f / sqrtf((xx + yy) + (zz + 0.0f)));
+                }
+                const float dir4[4] = { dir_hi[0], dir_hi[1], dir_hi[2], inv_w };
+                vo_raytrace(3, f->origin_hi, dir4, target, traced, &hi);
+            } else if (naive) {
                 if (target) vo_raycast_dense(f->origin_hi, dir_hi, target, 0, &hi);
                 else        vo_raycast_svo(f->origin_hi, dir_hi, target_svo, &hi);
             } else {
@@ -311,7 +380,18 @@ static void render_row(const volly_frame_desc *f, int y, const float row_hi[3], 
                 vo_raycast_beam(f->origin_lo, dir_hi, dir_lo, f->scale_lo_to_hi, low, target, target_svo, &lo, &hi);
             }
             size_t p = (size_t)(x - f->x0) + (size_t)(y - f->y0) * (size_t)f->tile_w;
-            if (o->rgba8)     o->rgba8[p] = hi.found ? vo_shade(hi.vox) : 255u;   /* u8vec4(255,0,0,0) */
+            if (o->rgba8) {
+                if (raytrace) {                           /* clamp to [0,1], u8vec4(255, rgb * 255.f) */
+                    uint32_t px = 255u;
+                    for (int c = 0; c < 3; ++c) {
+                        float v = fminf(fmaxf(traced[c], 0.0f), 1.0f);
+                        px |= (uint32_t)(uint8_t)(v * 255.f) << (8 * (c + 1));
+                    }
+                    o->rgba8[p] = px;
+                } else {
+                    o->rgba8[p] = hi.found ? vo_shade(hi.vox) : 255u;   /* u8vec4(255,0,0,0) */
+                }
+            }
             if (o->hit_index) o->hit_index[p] = hi.hit_index;
             if (o->steps_lo)  o->steps_lo[p] = naive ? 0u : lo.steps;
             if (o->steps_hi)  o->steps_hi[p] = hi.steps;
@@ -341,7 +421,8 @@ int vo_render_frame(const volly_frame_desc *f, const volly_dense_desc *low,
                     const volly_outputs *outs, int n_threads)
 {
     if (!f || !outs || (!target && !target_svo) || (target && target_svo)) return VOLLY_E_ARG;
-    if (!(f->flags & VOLLY_FRAME_NAIVE) && !low) return VOLLY_E_UNSUPPORTED;
+    if ((f->flags & VOLLY_FRAME_RAYTRACE) && !target) return VOLLY_E_UNSUPPORTED;
+    if (!(f->flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE)) && !low) return VOLLY_E_UNSUPPORTED;
     if (f->x0 < 0 || f->y0 < 0 || f->tile_w < 0 || f->tile_h < 0 ||
         f->x0 + f->tile_w > f->width || f->y0 + f->tile_h > f->height) return VOLLY_E_ARG;
 

@@ -45,6 +45,12 @@ void vo_raycast_dense(const float start[3], const float dir[3], const volly_dens
 void vo_raycast_svo(const float start[3], const float dir[3], const volly_svo_desc *svo,
                     vo_report *out);
 
+/* raytrace_naiive (main.cpp:170-194; dead code in the reference, its call site is commented
+ * out at main.cpp:274-278).  start xyz, direction xyzw (w takes part in reflect / refract /
+ * dot exactly as glm::vec4 does).  out = colour xyzw before the clamp of main.cpp:274. */
+void vo_raytrace(int iteration, const float start[3], const float direction[4], const volly_dense_desc *grid,
+                 float out[4], vo_report *primary);
+
 /* raycast_beamOpt (main.cpp:163-166); target is dense or svo (exactly one non-NULL). */
 void vo_raycast_beam(const float start_lo[3], const float dir_hi[3], const float dir_lo[3],
                      const float scale[3], const volly_dense_desc *low,

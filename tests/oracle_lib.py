@@ -36,6 +36,8 @@ lib.vo_raycast_svo.restype = None
 lib.vo_raycast_beam.argtypes = [_fp, _fp, _fp, _fp, C.POINTER(DenseDesc), C.POINTER(DenseDesc), C.POINTER(SvoDesc),
                                 C.POINTER(Report), C.POINTER(Report)]
 lib.vo_raycast_beam.restype = None
+lib.vo_raytrace.argtypes = [C.c_int, _fp, _fp, C.POINTER(DenseDesc), _fp, C.POINTER(Report)]
+lib.vo_raytrace.restype = None
 lib.vo_render_frame.argtypes = [C.POINTER(FrameDesc), C.POINTER(DenseDesc), C.POINTER(DenseDesc), C.POINTER(SvoDesc),
                                 C.POINTER(Outputs), C.c_int]
 lib.vo_render_frame.restype = C.c_int
@@ -76,6 +78,17 @@ def raycast_svo(start, direction, svo):
     r = Report()
     lib.vo_raycast_svo(sp, dp, C.byref(svo), C.byref(r))
     return r
+
+
+def raytrace(iteration, start, direction4, grid):
+    """raytrace_naiive (main.cpp:170-194): (colour xyzw, primary report)."""
+    s, sp = _f3(start)
+    d, dp = _f3(direction4)
+    assert d.size == 4
+    out = np.zeros(4, np.float32)
+    rep = Report()
+    lib.vo_raytrace(iteration, sp, dp, C.byref(grid), out.ctypes.data_as(_fp), C.byref(rep))
+    return out, rep
 
 
 _DT = {"rgba8": np.uint32, "hit_index": np.uint32, "steps_lo": np.uint32, "steps_hi": np.uint32, "depth": np.float32}

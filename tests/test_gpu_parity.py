@@ -307,3 +307,23 @@ def test_ray_refill_kernel(vra, ora, teapot64, sphere64, monkeypatch):
     gpu = vra.GpuScene.upload_dense(teapot64.target, teapot64.low)
     assert gpu.info(8) == 0
     gpu.close()
+
+
+def test_raytrace_frames(vra, ora, teapot64, sphere64):
+    """VOLLY_FRAME_RAYTRACE: raytrace_naiive (main.cpp:170-194) with the solid-mode traversal
+    raycast_naiive_vec4<true>; colour and primary-ray planes bit-exact against the oracle."""
+    for scene in (teapot64, sphere64):
+        hi, lo = _sizes(scene)
+        gpu = vra.GpuScene.upload_dense(scene.target, scene.low)
+        for k, radius in ((1, 1.0), (6, 0.7), (11, 0.45)):
+            pos, view = vra.orbit_camera(k, 16, radius)
+            f = vra.frame_from_camera(view, pos, hi, lo, 120, 67, raytrace=True)
+            want = ora.render_frame(f, target=scene.target)
+            assert_planes_equal({p: v[0] for p, v in gpu.render(f).items()}, want, f"raytrace view {k}")
+            assert (want["hit_index"] != MISS).sum() > 200
+        gpu.close()
+    svo = vra.GpuScene.upload_svo(teapot64.svo, teapot64.low)
+    with pytest.raises(vra.VollyError) as e:
+        svo.render(f)
+    assert e.value.code == -4
+    svo.close()

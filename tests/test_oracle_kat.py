@@ -146,3 +146,43 @@ def test_octree_and_dense_agree_on_hits_for_a_real_scene(vra, ora, teapot64):
     assert (a["hit_index"] != MISS).sum() > 500
     assert (a["hit_index"] == b["hit_index"]).mean() > 0.995
     assert b["steps_hi"].sum() < a["steps_hi"].sum() / 3      # the octree skips empty space
+
+
+def test_raytrace_known_values(vra, ora):
+    """raytrace_naiive (main.cpp:170-194) on a scene small enough to follow by hand.
+    One white voxel at (5,3,3) with normal bytes (254,127,127,0): the decoded normal is
+    n = b/127 - 1 = (1, 0, 0, -1) (w lane: 0/127 - 1).  A -x ray from (7.5,3.5,3.5) hits it.
+      iteration 1: colour = rgba/255 = (1,1,1,1).
+      iteration 2: d = dot(n, I) = -1; reflect = I - n*d*2 = (+1,0,0,-2): the reflected ray
+      leaves the grid (miss -> (0,0,0,1)); k = 1 - 4*(1 - 1) = 1, refract = 2I - (2d + 1)n =
+      (-1,0,0,-1): the solid pass walks out of the voxel; the continuation ray misses too.
+      colour = 0.35*(0,0,0,1) + 0*(0,0,0,1) + 0.65*(1,1,1,1) = (0.65, 0.65, 0.65, 1.0)."""
+    vox = np.zeros((8, 8, 8, 8), np.uint8)
+    vox[3, 3, 5] = (255, 255, 255, 255, 254, 127, 127, 0)
+    g = vra.host.dense_desc(vox)
+    c1, rep = ora.raytrace(1, (7.5, 3.5, 3.5), (-1, 0, 0, 0), g)
+    assert rep.found == 1 and tuple(rep.pt_end) == (6.0, 3.5, 3.5)
+    assert c1.tolist() == [1.0, 1.0, 1.0, 1.0]
+    c2, _ = ora.raytrace(2, (7.5, 3.5, 3.5), (-1, 0, 0, 0), g)
+    f = np.float32
+    diffuse = f(f(f(0.65) * f(255)) * f(f(1) / f(255)))
+    assert c2[:3].tolist() == [float(diffuse)] * 3
+    assert c2[3] == f(f(f(0.35) * f(1)) + f(0)) + diffuse
+    # a ray that hits nothing returns the background voxel's colour (0,0,0,255)/255
+    c0, rep0 = ora.raytrace(3, (7.5, 6.5, 6.5), (-1, 0, 0, 0), g)
+    assert rep0.found == 0 and c0.tolist() == [0.0, 0.0, 0.0, 1.0]
+
+
+def test_raytrace_frame_differs_from_plain_shading_only_in_colour(vra, ora, teapot64):
+    pos, view = vra.orbit_camera(2, 16, 1.0)
+    fr = vra.frame_from_camera(view, pos, (64,) * 3, (16,) * 3, 96, 64, raytrace=True)
+    fn = vra.frame_from_camera(view, pos, (64,) * 3, (16,) * 3, 96, 64, naive=True)
+    a = ora.render_frame(fr, target=teapot64.target)
+    b = ora.render_frame(fn, target=teapot64.target)
+    for p in ("hit_index", "steps_hi", "depth"):
+        assert np.array_equal(a[p].view(np.uint32), b[p].view(np.uint32))
+    hit = a["hit_index"] != MISS
+    assert hit.sum() > 300
+    assert (a["rgba8"][~hit] == 255).all()                      # miss: (0,0,0,1) -> u8vec4(255,0,0,0)
+    grey = (a["rgba8"][hit] >> 8) & 0xFF
+    assert grey.min() >= int(0.65 * 255) - 1                    # at least the diffuse share of a white voxel

@@ -187,8 +187,10 @@ int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, in
             return fail(VOLLY_E_ARG, "render: sub-rectangle outside the frame");
         if (f.tile_w != f0.tile_w || f.tile_h != f0.tile_h)
             return fail(VOLLY_E_ARG, "render: all frames of a call must share tile_w x tile_h");
-        if (f.flags & ~VOLLY_FRAME_NAIVE) return fail(VOLLY_E_ARG, "render: unknown frame flags");
-        if (!(f.flags & VOLLY_FRAME_NAIVE) && !s->has_low)
+        if (f.flags & ~(VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE)) return fail(VOLLY_E_ARG, "render: unknown frame flags");
+        if ((f.flags & VOLLY_FRAME_RAYTRACE) && s->is_svo)
+            return fail(VOLLY_E_UNSUPPORTED, "render: raytrace frames need a dense target (raytrace_naiive takes a VolumeStore)");
+        if (!(f.flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE)) && !s->has_low)
             return fail(VOLLY_E_UNSUPPORTED, "render: beam frame on a scene uploaded without a low grid");
     }
     if ((uint64_t)f0.tile_w * (uint64_t)f0.tile_h * (uint64_t)n_frames > (1ull << 40))
@@ -229,7 +231,9 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         HIP_TRY(hipEventRecord(e0, stream));
     }
     dim3 grid((unsigned)((tw + vk::kBlockW - 1) / vk::kBlockW), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
-    if (s->refill) {
+    bool any_raytrace = false;
+    for (int i = 0; i < n; ++i) any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
+    if (s->refill && !any_raytrace) {
         const unsigned tiles = (unsigned)groups * (unsigned)((th + vk::kTile - 1) / vk::kTile);
         const unsigned waves = (tiles + vk::kRaysPerWave / 64 - 1) / (vk::kRaysPerWave / 64);
         hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
@@ -237,6 +241,9 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     } else if (s->is_svo)
         hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
                            s->d_ckpt, o);
+    else if (any_raytrace)
+        hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low,
+                           s->d_frames, s->d_ckpt, o);
     else
         hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
                            s->d_ckpt, o);

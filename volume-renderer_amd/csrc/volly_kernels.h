@@ -168,6 +168,7 @@ struct Hit {
 // -1 < curPlusEpsilon < size, NaN failing, which is what is tested here.
 // This is the fully checked loop: it is right for every input, including direction
 // components that are zero, denormal or NaN (1/0 = inf, 0*inf = NaN inside the DDA).
+template <bool SOLID = false>
 __device__ __forceinline__ Hit trace_dense_checked(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
     Hit h;
@@ -187,7 +188,7 @@ __device__ __forceinline__ Hit trace_dense_checked(const DenseDev &g, const Ray 
 #if VK_AOS_SAMPLE
         (void)last_brick; (void)bits;
         const uint32_t idx = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
-        if ((g.vox[idx].x >> 24) != 0) {                 // VolumeStore::sample + rgba.a > 0, main.cpp:137-140
+        if (((g.vox[idx].x >> 24) != 0) != SOLID) {      // VolumeStore::sample + rgba.a > 0 (== 0 when solid), main.cpp:137-147
             h.index = idx;
             h.payload = idx;
             break;
@@ -199,7 +200,7 @@ __device__ __forceinline__ Hit trace_dense_checked(const DenseDev &g, const Ray 
             last_brick = brick;
         }
         uint32_t bit = (uint32_t)(x & 3) | ((uint32_t)(y & 3) << 2) | ((uint32_t)(z & 3) << 4);
-        if ((bits >> bit) & 1ull) {
+        if ((((bits >> bit) & 1ull) != 0) != SOLID) {    // main.cpp:139-147: solid looks for the first EMPTY voxel
             h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
             h.payload = h.index;
             break;
@@ -330,7 +331,7 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
         return trace_dense_regular<false>(g, r, ox, oy, oz);
     }
 #endif
-    return trace_dense_checked(g, r, ox, oy, oz);
+    return trace_dense_checked<false>(g, r, ox, oy, oz);
 }
 
 // Octree traversal (no reference implementation: svo.cpp:14-19 is empty).  Each
@@ -410,12 +411,13 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
     return h;
 }
 
-// glm::normalize(vec4(x,y,z,0)): v * (1/sqrt((xx+yy)+(zz+ww)))
-__device__ __forceinline__ void normalize_w0(float &x, float &y, float &z)
+// glm::normalize(vec4(x,y,z,0)): v * (1/sqrt((xx+yy)+(zz+ww))); returns the w component 0 * inversesqrt
+__device__ __forceinline__ float normalize_w0(float &x, float &y, float &z)
 {
     float d = (x * x + y * y) + (z * z + 0.0f);
     float inv = 1.0f / sqrtf(d);
     x = x * inv; y = y * inv; z = z * inv;
+    return 0.0f * inv;
 }
 
 // main.cpp:264-269
@@ -435,6 +437,63 @@ __device__ __forceinline__ uint32_t shade(uint2 vox)
     uint32_t cg = (uint32_t)((float)((vox.x >> 8) & 0xFFu) * l) & 0xFFu;
     uint32_t cb = (uint32_t)((float)((vox.x >> 16) & 0xFFu) * l) & 0xFFu;
     return 255u | (cr << 8) | (cg << 16) | (cb << 24);
+}
+
+// ---- raytrace_naiive, main.cpp:170-194 (dead code in the reference; its call site is the
+// commented block main.cpp:274-278).  glm::vec4 arithmetic including the w lanes: the decoded
+// normal has w = 0*(1/127) - 1 = -1, so w takes part in every dot / reflect / refract below.
+struct V4 { float x, y, z, w; };
+
+__device__ __forceinline__ float dot4(const V4 &a, const V4 &b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+template <int ITER>
+__device__ V4 raytrace(const DenseDev &g, float sx, float sy, float sz, V4 dir, Hit *primary)
+{
+    const float one_over_127 = 1.f / 127.f, one_over_255 = 1.f / 255.f;
+    const Ray r = make_ray(dir.x, dir.y, dir.z);
+    const Hit h = trace_dense_checked<false>(g, r, sx, sy, sz);
+    if (primary) *primary = h;
+    const bool found = h.index != VOLLY_MISS_INDEX;
+    uint2 vox = make_uint2(0xFF000000u, 0u);              // Voxel(bgColor) = (0,0,0,255), main.cpp:159
+    if (found) vox = g.vox[h.payload];
+    const float cr = (float)(vox.x & 0xFFu), cg = (float)((vox.x >> 8) & 0xFFu), cb = (float)((vox.x >> 16) & 0xFFu), ca = (float)(vox.x >> 24);
+    V4 out;
+    if constexpr (ITER <= 1) {
+        out.x = cr * one_over_255; out.y = cg * one_over_255; out.z = cb * one_over_255; out.w = ca * one_over_255;
+        return out;
+    } else {
+        if (!found) {                                     // main.cpp:177
+            out.x = cr * one_over_255; out.y = cg * one_over_255; out.z = cb * one_over_255; out.w = ca * one_over_255;
+            return out;
+        }
+        V4 n;                                             // main.cpp:179-180, unfused
+        n.x = (float)(vox.y & 0xFFu) * one_over_127 + -1.0f;
+        n.y = (float)((vox.y >> 8) & 0xFFu) * one_over_127 + -1.0f;
+        n.z = (float)((vox.y >> 16) & 0xFFu) * one_over_127 + -1.0f;
+        n.w = (float)(vox.y >> 24) * one_over_127 + -1.0f;
+        const float d = dot4(n, dir);
+        V4 refl;                                          // glm::reflect: I - N * dot(N, I) * 2
+        refl.x = dir.x - (n.x * d) * 2.f; refl.y = dir.y - (n.y * d) * 2.f;
+        refl.z = dir.z - (n.z * d) * 2.f; refl.w = dir.w - (n.w * d) * 2.f;
+        V4 refr = {0.f, 0.f, 0.f, 0.f};                   // glm::refract(I, N, 2)
+        const float eta = 2.f;
+        const float k = 1.f - (eta * eta) * (1.f - d * d);
+        if (k >= 0.f) {
+            const float f = eta * d + sqrtf(k);
+            refr.x = eta * dir.x - f * n.x; refr.y = eta * dir.y - f * n.y;
+            refr.z = eta * dir.z - f * n.z; refr.w = eta * dir.w - f * n.w;
+        }
+        const Ray rr = make_ray(refr.x, refr.y, refr.z);
+        const Hit hs = trace_dense_checked<true>(g, rr, h.cx, h.cy, h.cz);       // main.cpp:185, solid
+        const V4 c_refl = raytrace<ITER - 1>(g, h.cx, h.cy, h.cz, refl, nullptr);
+        const V4 c_refr = raytrace<ITER - 1>(g, hs.cx, hs.cy, hs.cz, dir, nullptr);
+        const float amt_reflect = 0.35f, amt_refract = 0.00f, amt_diffuse = 0.65f;
+        out.x = (amt_reflect * c_refl.x + amt_refract * c_refr.x) + (amt_diffuse * cr) * one_over_255;   // main.cpp:193
+        out.y = (amt_reflect * c_refl.y + amt_refract * c_refr.y) + (amt_diffuse * cg) * one_over_255;
+        out.z = (amt_reflect * c_refl.z + amt_refract * c_refr.z) + (amt_diffuse * cb) * one_over_255;
+        out.w = (amt_reflect * c_refl.w + amt_refract * c_refr.w) + (amt_diffuse * ca) * one_over_255;
+        return out;
+    }
 }
 
 // ---- pre-pass: serial ray-direction sums (main.cpp:254-255,282-286) -----------
@@ -476,7 +535,9 @@ direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames,
 }
 
 // ---- the frame kernel: main.cpp:256-272 for every pixel of the sub-rectangle --
-template <bool SVO>
+// RAYTRACE: the instantiation that can also serve VOLLY_FRAME_RAYTRACE frames (dense targets);
+// it needs 96 VGPRs, so frames of the live path never run through it.
+template <bool SVO, bool RAYTRACE = false>
 __global__ void __launch_bounds__(kThreads)
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
               const float *__restrict__ ckpt, OutDev out)
@@ -528,8 +589,27 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
             hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];
             lx = lx + fd.xdiff_lo[0]; ly = ly + fd.xdiff_lo[1]; lz = lz + fd.xdiff_lo[2];
         }
-        normalize_w0(hx, hy, hz);                         // main.cpp:260
+        const float hw = normalize_w0(hx, hy, hz);        // main.cpp:260
         const Ray ray_hi = make_ray(hx, hy, hz);
+        bool traced = false;
+        if constexpr (!SVO && RAYTRACE) {
+            if (fd.flags & VOLLY_FRAME_RAYTRACE) {        // main.cpp:274-278 (commented call site)
+                Hit prim;
+                const V4 col = raytrace<3>(target, fd.origin_hi[0], fd.origin_hi[1], fd.origin_hi[2], V4{hx, hy, hz, hw}, &prim);
+                const uint32_t tr = (uint32_t)(fminf(fmaxf(col.x, 0.0f), 1.0f) * 255.f) & 0xFFu;
+                const uint32_t tg = (uint32_t)(fminf(fmaxf(col.y, 0.0f), 1.0f) * 255.f) & 0xFFu;
+                const uint32_t tb = (uint32_t)(fminf(fmaxf(col.z, 0.0f), 1.0f) * 255.f) & 0xFFu;
+                o_rgba = 255u | (tr << 8) | (tg << 16) | (tb << 24);
+                o_shi = prim.steps;
+                o_hit = prim.index;
+                if (prim.index != VOLLY_MISS_INDEX) {
+                    float ddx = prim.cx - fd.origin_hi[0], ddy = prim.cy - fd.origin_hi[1], ddz = prim.cz - fd.origin_hi[2];
+                    o_depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
+                }
+                traced = true;
+            }
+        }
+        if (!traced) {
 
         float sx, sy, sz;                                 // start of the target-grid pass
         if (fd.flags & VOLLY_FRAME_NAIVE) {               // main.cpp:261
@@ -550,6 +630,7 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
             o_rgba = shade(vox);
             float ddx = hi.cx - fd.origin_hi[0], ddy = hi.cy - fd.origin_hi[1], ddz = hi.cz - fd.origin_hi[2];
             o_depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
+        }
         }
     }
 

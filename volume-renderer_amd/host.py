@@ -199,7 +199,7 @@ def orbit_camera(k, n, radius=1.2):
     return pos, view
 
 
-def frame_from_camera(view, cam_pos, size_hi, size_lo, width, height, naive=False):
+def frame_from_camera(view, cam_pos, size_hi, size_lo, width, height, naive=False, raytrace=False):
     """main.cpp:201-249 -> FrameDesc."""
     v, vp = _f(view, 16)
     p, pp = _f(cam_pos, 3)
@@ -209,6 +209,8 @@ def frame_from_camera(view, cam_pos, size_hi, size_lo, width, height, naive=Fals
     lib.volly_host_frame_from_camera(vp, pp, hi, lo, width, height, C.byref(out))
     if naive:
         out.flags = 1
+    if raytrace:
+        out.flags = 2
     return out
 
 
