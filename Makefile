@@ -18,6 +18,9 @@ HOST_SRC := $(PKG)/host/mesh.cpp $(PKG)/host/voxelize.cpp $(PKG)/host/tricube.cp
 HOST_HDR := $(PKG)/host/volly_scene.h $(PKG)/host/vollymath.h $(PKG)/host/tricube.h include/volly_host.h include/volly_gpu.h
 
 FPFLAGS  := -ffp-contract=off -fno-fast-math
+# the SLP vectorizer pairs the DDA's x/y float operations into v_pk_*_f32, which issue at half
+# rate on gfx950 and cost extra moves: measured 4-5 % slower (profiles/ab_bench.py, variant "slp")
+GPUFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(FPFLAGS) -fno-slp-vectorize -Iinclude
 
 all: gpu host oracle ref examples
 
@@ -27,8 +30,7 @@ oracle: oracle/libvolly_oracle.so
 
 $(LIBDIR)/libvolly_gpu.so: $(PKG)/csrc/volly_gpu.hip $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_refill.h include/volly_gpu.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(FPFLAGS) -Iinclude \
-	    -o $@ $(PKG)/csrc/volly_gpu.hip
+	$(HIPCC) $(GPUFLAGS) -o $@ $(PKG)/csrc/volly_gpu.hip
 
 $(LIBDIR)/libvolly_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
@@ -52,9 +54,9 @@ examples: examples/volly_headless
 VARDIR := $(LIBDIR)/variants
 variants:
 	@mkdir -p $(VARDIR)
-	for v in checked:-DVK_FAST_DDA=0 aos:-DVK_AOS_SAMPLE=1 linear:-DVK_LINEAR_TILE=1 xcd:-DVK_XCD_REMAP=1 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 'rootwalk_nolds:-DVK_SVO_TABLE=0 -DVK_LDS_TOP=0'; do \
+	for v in checked:-DVK_FAST_DDA=0 aos:-DVK_AOS_SAMPLE=1 'linear:-DVK_LINEAR_TILE=1 -DVK_WAVE_BLOCK=0' xcd:-DVK_XCD_REMAP=1 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 'rootwalk_nolds:-DVK_SVO_TABLE=0 -DVK_LDS_TOP=0' block256:-DVK_WAVE_BLOCK=0 slp:-fslp-vectorize; do \
 	  n=$${v%%:*}; f="$${v#*:}"; \
-	  $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(FPFLAGS) -Iinclude $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(PKG)/csrc/volly_gpu.hip || exit 1; \
+	  $(HIPCC) $(GPUFLAGS) $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(PKG)/csrc/volly_gpu.hip || exit 1; \
 	done
 
 # reference-style main loop on top of the C-ABI (links both libraries; rpath keeps it relocatable with the tree)

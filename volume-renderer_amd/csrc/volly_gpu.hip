@@ -239,13 +239,13 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
                            s->low, s->d_frames, s->d_ckpt, o);
     } else if (s->is_svo)
-        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
+        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
                            s->d_ckpt, o);
     else if (any_raytrace)
-        hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low,
+        hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low,
                            s->d_frames, s->d_ckpt, o);
     else
-        hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
+        hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
                            s->d_ckpt, o);
     HIP_TRY(hipGetLastError());
     if (s->profiling) {

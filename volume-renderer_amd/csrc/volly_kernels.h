@@ -2,9 +2,9 @@
 //
 // What the kernels compute is fixed by the reference (file:line cited at each
 // function); how they compute it is MI355X-first:
-//   * one ray per lane, one 64-lane wavefront per 8x8 pixel tile, four tiles side
-//     by side per 256-thread workgroup (a 32x8 pixel block, so every output row
-//     of the block is one 128-byte store per plane);
+//   * one ray per lane, one 64-lane wavefront per 8x8 pixel tile, one wavefront per
+//     workgroup: a wave retires as soon as its 64 rays are done (eight 32-byte row
+//     segments per store instruction; the L2 merges the neighbouring tiles' segments);
 //   * the dense grids are traversed through a derived 1-bit occupancy structure
 //     (4x4x4-voxel bricks, one 64-bit word each) kept beside the reference's 8-byte
 //     voxels; the 8-byte Voxel (voxel.h:13-16) is fetched once, at the hit.  A
@@ -34,6 +34,10 @@
 //   VK_LINEAR_TILE=1  a wavefront covers 64x1 pixels instead of 8x8
 //   VK_LDS_TOP=0      do not stage the top of the octree in LDS
 //   VK_XCD_REMAP=1    give each XCD (blockIdx % 8) one contiguous range of pixel blocks
+//   VK_WAVE_BLOCK=0   four wavefronts (a 32x8 pixel block) per workgroup with the output rows
+//                     staged through LDS into 128-byte stores, instead of one wavefront per
+//                     workgroup storing its 8x8 tile straight from registers (no barrier at
+//                     which finished waves wait for the slowest of the block)
 #ifndef VK_FAST_DDA
 #define VK_FAST_DDA 1
 #endif
@@ -55,13 +59,19 @@
 #ifndef VK_XCD_REMAP
 #define VK_XCD_REMAP 0
 #endif
+#ifndef VK_WAVE_BLOCK
+#define VK_WAVE_BLOCK 1
+#endif
+
+static_assert(!(VK_LINEAR_TILE && VK_WAVE_BLOCK), "the 32x2 wavefront tile needs the 32x8 workgroup (VK_WAVE_BLOCK=0)");
 
 namespace vk {
 
 constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
-constexpr int kBlockW = 32;         // workgroup covers 32 x 8 pixels
+constexpr int kBlockW = VK_WAVE_BLOCK ? 8 : 32;     // workgroup covers 8 x 8 (or 32 x 8) pixels
 constexpr int kBlockH = 8;
 constexpr int kThreads = 256;
+constexpr int kFrameThreads = VK_WAVE_BLOCK ? 64 : 256;   // workgroup size of render_frames
 constexpr int kTopNodes = VK_LDS_TOP ? 585 : 1;   // octree levels 0..3 (1 + 8 + 64 + 512 nodes) staged in LDS
 
 struct DenseDev {
@@ -538,16 +548,18 @@ direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames,
 // RAYTRACE: the instantiation that can also serve VOLLY_FRAME_RAYTRACE frames (dense targets);
 // it needs 96 VGPRs, so frames of the live path never run through it.
 template <bool SVO, bool RAYTRACE = false>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kFrameThreads)
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
               const float *__restrict__ ckpt, OutDev out)
 {
     __shared__ uint2 top[(SVO && !VK_SVO_TABLE) ? kTopNodes : 1];
+#if !VK_WAVE_BLOCK
     __shared__ uint32_t stage[5][kBlockH][kBlockW];
+#endif
 
     if (SVO && !VK_SVO_TABLE) {
         const uint32_t n = svo.n_nodes < (uint32_t)kTopNodes ? svo.n_nodes : (uint32_t)kTopNodes;
-        for (uint32_t i = threadIdx.x; i < n; i += kThreads) top[i] = svo.nodes[i];
+        for (uint32_t i = threadIdx.x; i < n; i += kFrameThreads) top[i] = svo.nodes[i];
         __syncthreads();
     }
 
@@ -634,6 +646,16 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
         }
     }
 
+#if VK_WAVE_BLOCK
+    if (active) {                                         // eight 32-byte row segments per store instruction
+        const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
+        if (out.rgba8) out.rgba8[p] = o_rgba;
+        if (out.hit_index) out.hit_index[p] = o_hit;
+        if (out.steps_lo) out.steps_lo[p] = o_slo;
+        if (out.steps_hi) out.steps_hi[p] = o_shi;
+        if (out.depth) out.depth[p] = o_depth;
+    }
+#else
     // framebuffer writeback: through LDS so that every store instruction writes
     // whole 128-byte row segments (main.cpp:269-271 writes data_stream[x + y*W])
     stage[0][py_in_block][px_in_block] = o_rgba;
@@ -652,6 +674,7 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
         if (out.steps_hi) out.steps_hi[p] = stage[3][wy][wx];
         if (out.depth) out.depth[p] = __uint_as_float(stage[4][wy][wx]);
     }
+#endif
 }
 
 // ---- scene preparation --------------------------------------------------------
