@@ -22,7 +22,7 @@ FPFLAGS  := -ffp-contract=off -fno-fast-math
 # rate on gfx950 and cost extra moves: measured 4-5 % slower (profiles/ab_bench.py, variant "slp")
 GPUFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $(FPFLAGS) -fno-slp-vectorize -Iinclude
 
-all: gpu host oracle ref examples
+all: gpu host oracle ref examples tools
 
 gpu: $(LIBDIR)/libvolly_gpu.so
 host: $(LIBDIR)/libvolly_host.so
@@ -50,11 +50,16 @@ oracle/_ref/libtricube_ref.so: oracle/tricube_ref_export.cpp $(REF)/triangleCube
 
 examples: examples/volly_headless
 
+# device-side exhaustive check of the short division / sqrt sequences the kernels use
+tools: tools/exhaustive_math
+tools/exhaustive_math: tools/exhaustive_math.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 $(FPFLAGS) -Wno-unused-result -o $@ $<
+
 # alternative builds of the kernels for A/B measurement (profiles/ab_bench.py); never loaded by the product
 VARDIR := $(LIBDIR)/variants
 variants:
 	@mkdir -p $(VARDIR)
-	for v in checked:-DVK_FAST_DDA=0 aos:-DVK_AOS_SAMPLE=1 'linear:-DVK_LINEAR_TILE=1 -DVK_WAVE_BLOCK=0' xcd:-DVK_XCD_REMAP=1 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 'rootwalk_nolds:-DVK_SVO_TABLE=0 -DVK_LDS_TOP=0' block256:-DVK_WAVE_BLOCK=0 slp:-fslp-vectorize; do \
+	for v in checked:-DVK_FAST_DDA=0 aos:-DVK_AOS_SAMPLE=1 'linear:-DVK_LINEAR_TILE=1 -DVK_WAVE_BLOCK=0' xcd:-DVK_XCD_REMAP=1 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 'rootwalk_nolds:-DVK_SVO_TABLE=0 -DVK_LDS_TOP=0' block256:-DVK_WAVE_BLOCK=0 longdiv:-DVK_SHORT_DIV=0 slp:-fslp-vectorize; do \
 	  n=$${v%%:*}; f="$${v#*:}"; \
 	  $(HIPCC) $(GPUFLAGS) $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(PKG)/csrc/volly_gpu.hip || exit 1; \
 	done
@@ -65,6 +70,6 @@ examples/volly_headless: examples/volly_headless.cpp $(PKG)/host/volly_state.h $
 	    -L$(LIBDIR) -lvolly_host -lvolly_gpu -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath-link,/opt/rocm/lib
 
 clean:
-	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref examples/volly_headless
+	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref examples/volly_headless tools/exhaustive_math
 
-.PHONY: all gpu host oracle ref examples variants clean
+.PHONY: all gpu host oracle ref examples tools variants clean

@@ -327,3 +327,22 @@ def test_raytrace_frames(vra, ora, teapot64, sphere64):
         svo.render(f)
     assert e.value.code == -4
     svo.close()
+
+
+def test_short_division_sequences_are_exact():
+    """The kernels replace the compiler's IEEE expansions of 1/d, sqrt(x) and n/255 by short
+    sequences for operands in [2^-100, 2^100] (volly_kernels.h: rcp_in_range, sqrt_in_range,
+    over_255).  tools/exhaustive_math runs all 2^32 binary32 patterns through both on the
+    device: the sequences in use must not differ once inside that range."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "exhaustive_math")
+    if not os.path.exists(exe):
+        pytest.fail("tools/exhaustive_math is not built (make tools)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    bad = {m.group(1): int(m.group(2)) for m in re.finditer(r"^(\S+)\s+mismatches in range (\d+)", r.stdout, re.M)}
+    assert bad["rcp_a"] == 0 and bad["sqrt_candidates"] == 0, r.stdout
+    m = re.search(r"n/255 refined: (\d+) mismatches", r.stdout)
+    assert m and int(m.group(1)) == 0, r.stdout

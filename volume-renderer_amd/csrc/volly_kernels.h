@@ -34,6 +34,7 @@
 //   VK_LINEAR_TILE=1  a wavefront covers 64x1 pixels instead of 8x8
 //   VK_LDS_TOP=0      do not stage the top of the octree in LDS
 //   VK_XCD_REMAP=1    give each XCD (blockIdx % 8) one contiguous range of pixel blocks
+//   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
 //   VK_WAVE_BLOCK=0   four wavefronts (a 32x8 pixel block) per workgroup with the output rows
 //                     staged through LDS into 128-byte stores, instead of one wavefront per
 //                     workgroup storing its 8x8 tile straight from registers (no barrier at
@@ -61,6 +62,9 @@
 #endif
 #ifndef VK_WAVE_BLOCK
 #define VK_WAVE_BLOCK 1
+#endif
+#ifndef VK_SHORT_DIV
+#define VK_SHORT_DIV 1
 #endif
 
 static_assert(!(VK_LINEAR_TILE && VK_WAVE_BLOCK), "the 32x2 wavefront tile needs the 32x8 workgroup (VK_WAVE_BLOCK=0)");
@@ -107,7 +111,53 @@ struct Ray {
     float ix, iy, iz;               // 1/direction
     float hx, hy, hz;               // heaviside: 0 for a negative component, else 1
     float ex, ey, ez;               // sign * eps
+    bool regular;                   // every component a normal float with 2^-100 <= |d| <= 2
 };
+
+// ---- correctly rounded 1/d, sqrt(x), n/255 in a few instructions ------------------
+// The compiler expands an IEEE division into 10 and a square root into 17 vector
+// instructions, most of them there for denormal / huge / special operands.  For operands in
+// [2^-100, 2^100] the short sequences below give the SAME bits: tools/exhaustive_math.hip
+// compares them with the full expansions on every one of the 2^32 binary32 patterns on the
+// device (tests/test_gpu_parity.py::test_short_division_sequences_are_exact), 0 mismatches in
+// that range.  Operands outside it take the full expansion.
+constexpr float kFastLo = 7.888609052210118e-31f;   // 2^-100
+constexpr float kFastHi = 1.2676506002282294e30f;   // 2^100
+
+__device__ __forceinline__ bool in_fast_range(float x)
+{
+    float a = fabsf(x);
+    return (a >= kFastLo) & (a <= kFastHi);              // NaN fails
+}
+
+__device__ __forceinline__ float rcp_in_range(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);                   // 1 ulp
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
+__device__ __forceinline__ float sqrt_in_range(float x)  // x > 0
+{
+    float s = __builtin_amdgcn_sqrtf(x);                  // 1 ulp: the result is s or a neighbour
+    float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    float em = __builtin_fmaf(-sm, s, x), ep = __builtin_fmaf(-sp, s, x);
+    float r = (em <= 0.0f) ? sm : s;
+    return (ep > 0.0f) ? sp : r;
+}
+
+// x / 255.0f for x = 0, 1, ..., 255 (all 256 cases checked by the same tool)
+__device__ __forceinline__ float over_255(float x)
+{
+#if VK_SHORT_DIV
+    const float r = 1.0f / 255.0f;
+    float q = x * r;
+    float e = __builtin_fmaf(-255.0f, q, x);
+    return __builtin_fmaf(e, r, q);
+#else
+    return x / 255.0f;
+#endif
+}
 
 // main.cpp:96-102
 __device__ __forceinline__ Ray make_ray(float dx, float dy, float dz)
@@ -115,7 +165,16 @@ __device__ __forceinline__ Ray make_ray(float dx, float dy, float dz)
     const float eps = 0.00030f;
     Ray r;
     r.dx = dx; r.dy = dy; r.dz = dz;
-    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    {
+        const float lo = kFastLo, hi = 2.0f;
+        float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+        r.regular = (ax >= lo) & (ax <= hi) & (ay >= lo) & (ay <= hi) & (az >= lo) & (az <= hi);     // NaN fails
+    }
+    if (VK_SHORT_DIV && r.regular) {
+        r.ix = rcp_in_range(dx); r.iy = rcp_in_range(dy); r.iz = rcp_in_range(dz);
+    } else {
+        r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    }
     // heaviside = round((sign+1)/2): 0 for sign -1, 1 for sign +1 and, rounding half away from zero, for sign 0
     r.hx = (dx < 0.0f) ? 0.0f : 1.0f;
     r.hy = (dy < 0.0f) ? 0.0f : 1.0f;
@@ -225,12 +284,7 @@ __device__ __forceinline__ Hit trace_dense_checked(const DenseDev &g, const Ray 
 // >= 2^-100 (so 1/d is finite).  For such a ray, once one bounds check has passed,
 // every quantity of the DDA stays finite and each step moves every coordinate by at
 // most one cell; the loop below relies on both.
-__device__ __forceinline__ bool ray_is_regular(const Ray &r)
-{
-    const float lo = 7.9e-31f, hi = 2.0f;
-    float ax = fabsf(r.dx), ay = fabsf(r.dy), az = fabsf(r.dz);
-    return (ax >= lo) & (ax <= hi) & (ay >= lo) & (ay <= hi) & (az >= lo) & (az <= hi);     // NaN fails
-}
+__device__ __forceinline__ bool ray_is_regular(const Ray &r) { return r.regular; }
 
 __device__ __forceinline__ bool grid_is_regular(const DenseDev &g)
 {
@@ -425,7 +479,9 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
 __device__ __forceinline__ float normalize_w0(float &x, float &y, float &z)
 {
     float d = (x * x + y * y) + (z * z + 0.0f);
-    float inv = 1.0f / sqrtf(d);
+    float inv;
+    if (VK_SHORT_DIV && in_fast_range(d)) inv = rcp_in_range(sqrt_in_range(d));   // sqrt of [2^-100, 2^100] lies in [2^-50, 2^50]
+    else inv = 1.0f / sqrtf(d);
     x = x * inv; y = y * inv; z = z * inv;
     return 0.0f * inv;
 }
@@ -436,10 +492,10 @@ __device__ __forceinline__ uint32_t shade(uint2 vox)
     float inv = 1.0f / sqrtf((1.0f + 1.0f) + (1.0f + 0.0f));
     float sun = 1.0f * inv;
     float sun_w = 0.0f * inv;
-    float nx = (float)(vox.y & 0xFFu) / 255.0f;
-    float ny = (float)((vox.y >> 8) & 0xFFu) / 255.0f;
-    float nz = (float)((vox.y >> 16) & 0xFFu) / 255.0f;
-    float nw = (float)(vox.y >> 24) / 255.0f;
+    float nx = over_255((float)(vox.y & 0xFFu));
+    float ny = over_255((float)((vox.y >> 8) & 0xFFu));
+    float nz = over_255((float)((vox.y >> 16) & 0xFFu));
+    float nw = over_255((float)(vox.y >> 24));
     float d = (sun * nx + sun * ny) + (sun * nz + sun_w * nw);
     float l = d / 2.0f + 0.5f;
     l = fminf(fmaxf(l, 0.0f), 1.0f);
