@@ -28,9 +28,12 @@ gpu: $(LIBDIR)/libvolly_gpu.so
 host: $(LIBDIR)/libvolly_host.so
 oracle: oracle/libvolly_oracle.so
 
-$(LIBDIR)/libvolly_gpu.so: $(PKG)/csrc/volly_gpu.hip $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_refill.h include/volly_gpu.h
+GPU_SRC := $(PKG)/csrc/volly_gpu.hip $(PKG)/csrc/volly_voxelize.hip
+GPU_HDR := $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_refill.h $(PKG)/csrc/volly_internal.h include/volly_gpu.h
+
+$(LIBDIR)/libvolly_gpu.so: $(GPU_SRC) $(GPU_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(GPUFLAGS) -o $@ $(PKG)/csrc/volly_gpu.hip
+	$(HIPCC) $(GPUFLAGS) -o $@ $(GPU_SRC)
 
 $(LIBDIR)/libvolly_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
@@ -61,7 +64,7 @@ variants:
 	@mkdir -p $(VARDIR)
 	for v in checked:-DVK_FAST_DDA=0 aos:-DVK_AOS_SAMPLE=1 'linear:-DVK_LINEAR_TILE=1 -DVK_WAVE_BLOCK=0' xcd:-DVK_XCD_REMAP=1 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 'rootwalk_nolds:-DVK_SVO_TABLE=0 -DVK_LDS_TOP=0' block256:-DVK_WAVE_BLOCK=0 longdiv:-DVK_SHORT_DIV=0 slp:-fslp-vectorize; do \
 	  n=$${v%%:*}; f="$${v#*:}"; \
-	  $(HIPCC) $(GPUFLAGS) $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(PKG)/csrc/volly_gpu.hip || exit 1; \
+	  $(HIPCC) $(GPUFLAGS) $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(GPU_SRC) || exit 1; \
 	done
 
 # reference-style main loop on top of the C-ABI (links both libraries; rpath keeps it relocatable with the tree)

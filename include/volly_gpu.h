@@ -143,6 +143,35 @@ int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, in
 int volume_gpu_render_device(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames,
                              const volly_outputs *outs, void *hip_stream);
 
+/* Scene preparation on the device: the voxelization of Vol_LOD_Set's constructor
+ * (main.cpp:23-50) for one target resolution -- rasterizeVoxelMapFromPoly
+ * (PLYfileReader.cpp:218-321) with t_c_intersection (triangleCube.c:213-319),
+ * volumeFromVoxelMap (volume.h:114-123) for the target (LoD 0, res^3) and the low
+ * beam grid (LoD 2, (res/4)^3, main.cpp:33), and the octree builder -- producing a
+ * scene ready to render with no voxel ever crossing PCIe.  `mesh` is the polyhedron
+ * AFTER normalizePoly (PLYfileReader.cpp:141-171): n_verts x (x,y,z,w) floats and
+ * n_tris x 3 vertex indices (volly_host_mesh_* in volly_host.h prepares it the
+ * way the host pipeline would).  flags: VOLLY_VOX_DENSE and/or VOLLY_VOX_SVO
+ * (rendering uses the octree when both are present).  res: multiple of 4 in
+ * [8, 4096].  The grids and the octree equal the host pipeline's byte for byte
+ * (tests/test_gpu_voxelize.py); the reference's per-triangle flood fill runs as
+ * one breadth-first search over all triangles at once.
+ * stats (optional, 8 values): triangles used, cells tested, (cell, triangle)
+ * pairs that passed, search levels, distinct LoD-0 cells, microseconds spent in the
+ * call, peak bytes of device scratch, 0. */
+typedef struct volly_mesh_desc {
+    int64_t n_verts;
+    const float *verts;             /* n_verts * 4 floats */
+    int64_t n_tris;
+    const int32_t *tris;            /* n_tris * 3 vertex indices */
+} volly_mesh_desc;
+
+#define VOLLY_VOX_DENSE 1
+#define VOLLY_VOX_SVO   2
+
+int volume_gpu_voxelize(int device, const volly_mesh_desc *mesh, int32_t res, int32_t flags,
+                        volly_gpu_scene **out, int64_t *stats);
+
 /* Kernel timing with HIP events on the stream the kernels are launched on.
  * While enabled every traversal-kernel launch is bracketed by an event pair;
  * volly_gpu_kernel_time waits for them, returns the summed milliseconds and the
@@ -154,9 +183,15 @@ int volly_gpu_kernel_time(volly_gpu_scene *scene, double *ms_total, int *launche
  * index `first` back to the host (checks of generated / uploaded scenes). */
 int volly_gpu_read_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count, void *out);
 
+/* Same for the low (beam) grid, and for the octree arrays (either pointer may be
+ * null; sizes from volly_gpu_scene_info 10 / 11). */
+int volly_gpu_read_low_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count, void *out);
+int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leaves);
+
 /* Scene facts: 0 sx, 1 sy, 2 sz, 3 is_svo, 4 has_low, 5 low sx, 6 device,
  * 7 device bytes held (MiB), 8 frame kernel (0 tile per wavefront, 1 ray refill),
- * 9 target grid uses the 16^3 region level. */
+ * 9 target grid uses the 16^3 region level, 10 octree nodes, 11 octree leaves,
+ * 12 octree depth, 13 a dense target grid is held. */
 int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
 
 void        volly_gpu_free(volly_gpu_scene *scene);

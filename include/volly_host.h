@@ -48,6 +48,17 @@ void volly_host_scene_free(volly_host_scene *s);
 int volly_host_scene_save(const volly_host_scene *s, const char *path);
 volly_host_scene *volly_host_scene_load(const char *path);
 
+/* A mesh as rasterizeVoxelMapFromPoly would see it, for volume_gpu_voxelize (volly_gpu.h):
+ * readPLYFile / the OFF reader, then normalizePoly (PLYfileReader.cpp:141-171) applied
+ * n_normalize times -- the reference normalises once in Vol_LOD_Set's constructor
+ * (main.cpp:27) and once more at the top of every rasterize call (PLYfileReader.cpp:219),
+ * so the grid built first sees 2 (what volly_host_scene_from_mesh does) and `high` sees 3.
+ * The descriptor points into the handle. */
+typedef struct volly_host_mesh volly_host_mesh;
+volly_host_mesh *volly_host_mesh_load(const char *path, int32_t n_normalize);
+int  volly_host_mesh_view(const volly_host_mesh *m, volly_mesh_desc *out);
+void volly_host_mesh_free(volly_host_mesh *m);
+
 /* The reference's default four-grid set (main.h:79: 16/32/128/256); which = 0..3 = arr[] */
 typedef struct volly_host_lod_set volly_host_lod_set;
 volly_host_lod_set *volly_host_lod_set_load(const char *path, int32_t sLowR, int32_t lowR, int32_t medR, int32_t highR);

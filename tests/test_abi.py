@@ -45,6 +45,7 @@ def test_struct_layouts_match_the_c_compiler(vra, tmp_path):
                                              "origin_lo", "origin_hi", "scale_lo_to_hi", "width", "height", "x0",
                                              "y0", "tile_w", "tile_h", "flags", "reserved"]),
         "volly_outputs": (abi.Outputs, ["rgba8", "hit_index", "steps_lo", "steps_hi", "depth"]),
+        "volly_mesh_desc": (abi.MeshDesc, ["n_verts", "verts", "n_tris", "tris"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "volly_gpu.h"', 'int main(void){']
     for cname, (_, fields) in structs.items():

@@ -1,0 +1,85 @@
+"""volume_gpu_voxelize: scene preparation on the device against the host
+pipeline, which test_host.py pins to a literal restatement of the reference's
+rasterizeVoxelMapFromPoly and to the reference's own triangleCube.c.  Everything is compared
+byte for byte: target grid, low beam grid, octree nodes and leaves, and a rendered frame."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_and_gpu(vra, mesh, res, dense, svo=True):
+    path = os.path.join(ASSETS, mesh)
+    host = vra.HostScene.from_mesh(path, res, dense=dense, svo=svo)
+    hm = vra.HostMesh(path, 2)
+    gpu = vra.GpuScene.voxelize(hm.desc, res, dense=dense, svo=svo)
+    return host, hm, gpu
+
+
+@pytest.mark.parametrize("mesh,res", [("icosahedron.ply", 32), ("icosahedron.off", 64), ("teapot.off", 128),
+                                      ("galleon.ply", 128), ("stratocaster.ply", 256), ("dragon.off", 256)])
+def test_grids_and_octree_equal_the_host_pipeline(vra, mesh, res):
+    host, hm, gpu = _host_and_gpu(vra, mesh, res, dense=True)
+    st = gpu.vox_stats
+    assert st["triangles"] > 0 and st["tests"] >= st["pairs"] > 0 and st["levels"] > 0
+    # target grid (volumeFromVoxelMap LoD 0)
+    want = vra.host.dense_view(host.target).reshape(-1, 8)
+    got = gpu.read_voxels(0, res ** 3)
+    assert np.array_equal(got, want), f"{int((got != want).any(axis=1).sum())} target voxels differ"
+    assert st["cells"] >= int((want[:, 3] > 0).sum())
+    # low beam grid (LoD 2 at res/4, with the reference's x > 1 and -1/2 == 0 quirks)
+    want_lo = vra.host.dense_view(host.low).reshape(-1, 8)
+    got_lo = gpu.read_low_voxels()
+    assert np.array_equal(got_lo, want_lo), f"{int((got_lo != want_lo).any(axis=1).sum())} low voxels differ"
+    assert int((want_lo[:, 3] > 0).sum()) > 0
+    # octree
+    nodes_h, leaves_h = host.svo_arrays()
+    nodes_g, leaves_g = gpu.read_svo()
+    assert gpu.info(12) == host.svo.depth
+    assert nodes_g.shape == nodes_h.shape and leaves_g.shape == leaves_h.shape
+    assert np.array_equal(nodes_g.view(np.uint64), nodes_h.view(np.uint64))
+    assert np.array_equal(leaves_g, leaves_h)
+    gpu.close()
+    hm.close()
+    host.close()
+
+
+def test_octree_only_scene_renders_like_the_uploaded_one(vra):
+    res = 256
+    host, hm, gpu = _host_and_gpu(vra, "dragon.off", res, dense=False)
+    assert gpu.info(13) == 0 and gpu.info(3) == 1
+    up = vra.GpuScene.upload_svo(host.svo, host.low)
+    frames = vra.orbit_frames([100, 1500], 4096, (res,) * 3, (res // 4,) * 3, 320, 200)
+    a, b = gpu.render(frames), up.render(frames)
+    for p in a:
+        assert np.array_equal(a[p].view(np.uint32), b[p].view(np.uint32)), p
+    assert int((a["hit_index"] != 0xFFFFFFFF).sum()) > 1000
+    for s in (gpu, up, hm, host):
+        s.close()
+
+
+def test_large_octree_matches_the_host(vra):
+    """BASELINE config 2's scene (dragon 512^3) built on the device."""
+    host, hm, gpu = _host_and_gpu(vra, "dragon.off", 512, dense=False)
+    nodes_h, leaves_h = host.svo_arrays()
+    nodes_g, leaves_g = gpu.read_svo()
+    assert np.array_equal(nodes_g.view(np.uint64), nodes_h.view(np.uint64))
+    assert np.array_equal(leaves_g, leaves_h)
+    assert np.array_equal(gpu.read_low_voxels(), vra.host.dense_view(host.low).reshape(-1, 8))
+    for s in (gpu, hm, host):
+        s.close()
+
+
+def test_argument_errors(vra):
+    hm = vra.HostMesh(os.path.join(ASSETS, "icosahedron.ply"), 2)
+    with pytest.raises(vra.VollyError):
+        vra.GpuScene.voxelize(hm.desc, 30)                 # not a multiple of 4
+    with pytest.raises(vra.VollyError):
+        vra.GpuScene.voxelize(hm.desc, 64, dense=False, svo=False)
+    with pytest.raises(vra.VollyError):
+        vra.GpuScene.voxelize(hm.desc, 8192)
+    hm.close()

@@ -10,5 +10,5 @@ Python here is plumbing only (ctypes over the two shared libraries):
   gpu   -> lib/libvolly_gpu.so   HIP kernels + C-ABI; import fails loudly if it is missing.
 """
 from . import host, gpu, shard   # noqa: F401
-from .host import HostScene, LodSet, frame_from_camera, orbit_camera, look_at, orbit_frames  # noqa: F401
+from .host import HostScene, HostMesh, LodSet, frame_from_camera, orbit_camera, look_at, orbit_frames  # noqa: F401
 from .gpu import GpuScene, VollyError  # noqa: F401

@@ -16,6 +16,8 @@ FRAME_BEAM = 0
 FRAME_NAIVE = 1
 SCENE_DENSE = 1
 SCENE_SVO = 2
+VOX_DENSE = 1
+VOX_SVO = 2
 
 
 class DenseDesc(C.Structure):
@@ -30,6 +32,10 @@ class SvoNode(C.Structure):
 class SvoDesc(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("depth", C.c_int32), ("res", C.c_int32),
                 ("nodes", C.c_void_p), ("leaves", C.c_void_p)]
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [("n_verts", C.c_int64), ("verts", C.c_void_p), ("n_tris", C.c_int64), ("tris", C.c_void_p)]
 
 
 class FrameDesc(C.Structure):

@@ -1,6 +1,6 @@
 // volly_gpu.hip -- C-ABI of the MI355X traversal path (include/volly_gpu.h).
 // Built for gfx950 only, with -ffp-contract=off (see volly_kernels.h).
-#include "volly_kernels.h"
+#include "volly_internal.h"
 #include "volly_refill.h"
 
 #include <algorithm>
@@ -12,64 +12,17 @@
 #include <utility>
 #include <vector>
 
-namespace {
-
+namespace vimpl {
 thread_local std::string g_err;
-
-int fail(int code, const std::string &msg)
-{
-    g_err = msg;
-    return code;
 }
 
-#define HIP_TRY(expr)                                                                             \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return fail(e_ == hipErrorOutOfMemory ? VOLLY_E_NOMEM : VOLLY_E_HIP,                  \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
-    } while (0)
-
-// remembers the caller's current device and puts it back
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-constexpr int kFrameChunk = 32;     // frames per launch (bounds the checkpoint scratch)
-
-} // namespace
-
-struct volly_gpu_scene {
-    int device = 0;
-    bool is_svo = false, has_low = false;
-    bool refill = false;            // incoherent dense scene: use the ray-refill frame kernel
-    vk::DenseDev target{}, low{};
-    vk::SvoDev svo{};
-    // owned device allocations
-    std::vector<void *> owned;
-    size_t bytes = 0;
-    // per-call scratch
-    volly_frame_desc *d_frames = nullptr;
-    float *d_ckpt = nullptr;
-    size_t ckpt_floats = 0;
-    void *d_planes = nullptr;       // staging of the synchronous entry point
-    size_t plane_bytes = 0;
-    // profiling
-    bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-};
+using namespace vimpl;
 
 namespace {
+constexpr int kFrameChunk = 32;     // frames per launch (bounds the checkpoint scratch)
+}
+
+namespace vimpl {
 
 int dev_alloc(volly_gpu_scene *s, void **p, size_t bytes)
 {
@@ -79,6 +32,16 @@ int dev_alloc(volly_gpu_scene *s, void **p, size_t bytes)
     return VOLLY_OK;
 }
 
+void adopt(volly_gpu_scene *s, void *p, size_t bytes)
+{
+    s->owned.push_back(p);
+    s->bytes += bytes;
+}
+
+} // namespace vimpl
+
+namespace {
+
 int check_dense(const volly_dense_desc *d, const char *what)
 {
     if (!d || !d->voxels) return fail(VOLLY_E_ARG, std::string(what) + ": null grid");
@@ -87,6 +50,10 @@ int check_dense(const volly_dense_desc *d, const char *what)
         return fail(VOLLY_E_ARG, std::string(what) + ": more than 2^31 voxels (the reference indexes with int, volume.h:79-81)");
     return VOLLY_OK;
 }
+
+} // namespace
+
+namespace vimpl {
 
 // upload (or adopt) the 8-byte voxels of one grid and derive its occupancy bricks
 int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox, uint2 *dev_vox, vk::DenseDev *out)
@@ -159,7 +126,7 @@ int new_scene(int device, volly_gpu_scene **out)
     return VOLLY_OK;
 }
 
-bool host_grid_is_regular(const vk::DenseDev &g)
+static bool host_grid_is_regular(const vk::DenseDev &g)
 {
     return ((g.sx | g.sy | g.sz) & 15) == 0 && g.sx <= 1024 && g.sy <= 1024 && g.sz <= 1024;
 }
@@ -175,6 +142,34 @@ void choose_frame_kernel(volly_gpu_scene *s)
     if (const char *e = std::getenv("VOLLY_REFILL")) want = ok && std::atoi(e) != 0;
     s->refill = want;
 }
+
+int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res)
+{
+    s->is_svo = true;
+    s->svo.nodes = nodes; s->svo.leaves = leaves;
+    s->svo.n_nodes = n_nodes;
+    s->n_leaves = n_leaves;
+    s->svo.depth = depth; s->svo.res = res; s->svo.fres = (float)res;
+    s->svo.cap = 4u * (uint32_t)(3 * res) + 8u;
+    s->target.sx = s->target.sy = s->target.sz = res;
+    // direct-index table of the upper levels: cells of 2^tshift voxels, at most 128^3 entries
+    int tbits = std::min(std::max(depth - 3, 0), 7);
+    if (const char *e = std::getenv("VOLLY_SVO_TABLE_BITS")) tbits = std::min(std::max(std::atoi(e), 0), std::min(depth - 1, 8));
+    s->svo.tbits = tbits;
+    s->svo.tshift = depth - tbits;
+    const size_t nt = (size_t)1 << (3 * tbits);
+    uint32_t *table = nullptr;
+    int rc = dev_alloc(s, (void **)&table, nt * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vk::build_svo_table, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, nodes, depth, tbits, s->svo.tshift, table);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(VOLLY_E_HIP, "build_svo_table failed");
+    s->svo.table = table;
+    return VOLLY_OK;
+}
+
+} // namespace vimpl
+
+namespace {
 
 int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, int n_frames)
 {
@@ -331,27 +326,7 @@ int svo_gpu_upload(int device, const volly_svo_desc *svo, const volly_dense_desc
         rc = fail(VOLLY_E_HIP, "svo_gpu_upload: node copy failed");
     if (!rc && svo->n_leaves && hipMemcpy(leaves, svo->leaves, (size_t)svo->n_leaves * 8, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(VOLLY_E_HIP, "svo_gpu_upload: leaf copy failed");
-    if (!rc) {
-        s->svo.nodes = nodes; s->svo.leaves = leaves;
-        s->svo.n_nodes = svo->n_nodes;
-        s->svo.depth = svo->depth; s->svo.res = svo->res; s->svo.fres = (float)svo->res;
-        s->svo.cap = 4u * (uint32_t)(3 * svo->res) + 8u;
-        s->target.sx = s->target.sy = s->target.sz = svo->res;
-        // direct-index table of the upper levels: cells of 2^tshift voxels, at most 128^3 entries
-        int tbits = std::min(std::max(svo->depth - 3, 0), 7);
-        if (const char *e = std::getenv("VOLLY_SVO_TABLE_BITS")) tbits = std::min(std::max(std::atoi(e), 0), std::min(svo->depth - 1, 8));
-        s->svo.tbits = tbits;
-        s->svo.tshift = svo->depth - tbits;
-        const size_t nt = (size_t)1 << (3 * tbits);
-        uint32_t *table = nullptr;
-        rc = dev_alloc(s, (void **)&table, nt * 4);
-        if (!rc) {
-            hipLaunchKernelGGL(vk::build_svo_table, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, nodes, svo->depth, tbits,
-                               s->svo.tshift, table);
-            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(VOLLY_E_HIP, "build_svo_table failed");
-            s->svo.table = table;
-        }
-    }
+    if (!rc) rc = finish_svo(s, nodes, leaves, svo->n_nodes, (uint32_t)svo->n_leaves, svo->depth, svo->res);
     if (!rc && low) {
         rc = make_dense(s, low->sx, low->sy, low->sz, low->voxels, nullptr, &s->low);
         s->has_low = true;
@@ -466,10 +441,31 @@ int volly_gpu_kernel_time(volly_gpu_scene *scene, double *ms_total, int *launche
     return VOLLY_OK;
 }
 
+int volly_gpu_read_low_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count, void *out)
+{
+    if (!scene || !out) return fail(VOLLY_E_ARG, "null argument");
+    if (!scene->has_low) return fail(VOLLY_E_UNSUPPORTED, "scene has no low grid");
+    const uint64_t n = (uint64_t)scene->low.sx * scene->low.sy * scene->low.sz;
+    if (first > n || count > n - first) return fail(VOLLY_E_ARG, "range outside the grid");
+    DeviceGuard g(scene->device);
+    HIP_TRY(hipMemcpy(out, scene->low.vox + first, count * 8, hipMemcpyDeviceToHost));
+    return VOLLY_OK;
+}
+
+int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leaves)
+{
+    if (!scene) return fail(VOLLY_E_ARG, "null argument");
+    if (!scene->svo.nodes) return fail(VOLLY_E_UNSUPPORTED, "scene has no octree");
+    DeviceGuard g(scene->device);
+    if (nodes) HIP_TRY(hipMemcpy(nodes, scene->svo.nodes, (size_t)scene->svo.n_nodes * 8, hipMemcpyDeviceToHost));
+    if (leaves && scene->n_leaves) HIP_TRY(hipMemcpy(leaves, scene->svo.leaves, (size_t)scene->n_leaves * 8, hipMemcpyDeviceToHost));
+    return VOLLY_OK;
+}
+
 int volly_gpu_read_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count, void *out)
 {
     if (!scene || !out) return fail(VOLLY_E_ARG, "null argument");
-    if (scene->is_svo) return fail(VOLLY_E_UNSUPPORTED, "scene has no dense target");
+    if (!scene->target.vox) return fail(VOLLY_E_UNSUPPORTED, "scene has no dense target");
     const uint64_t n = (uint64_t)scene->target.sx * scene->target.sy * scene->target.sz;
     if (first > n || count > n - first) return fail(VOLLY_E_ARG, "range outside the grid");
     DeviceGuard g(scene->device);
@@ -491,6 +487,10 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 7: return (int64_t)(s->bytes >> 20);
     case 8: return s->refill;
     case 9: return s->is_svo ? 0 : s->target.use_regions;
+    case 10: return s->svo.nodes ? (int64_t)s->svo.n_nodes : 0;
+    case 11: return s->svo.nodes ? (int64_t)s->n_leaves : 0;
+    case 12: return s->svo.nodes ? s->svo.depth : 0;
+    case 13: return s->target.vox != nullptr;
     default: return -1;
     }
 }

@@ -1,0 +1,83 @@
+// volly_internal.h -- shared by the translation units of libvolly_gpu.so (not installed).
+#ifndef VOLLY_INTERNAL_H
+#define VOLLY_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <string>
+#include <utility>
+#include <vector>
+#include "volly_gpu.h"
+#include "volly_kernels.h"
+
+namespace vimpl {
+
+extern thread_local std::string g_err;
+
+inline int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return vimpl::fail(e_ == hipErrorOutOfMemory ? VOLLY_E_NOMEM : VOLLY_E_HIP,           \
+                               std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+// remembers the caller's current device and puts it back
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+} // namespace vimpl
+
+struct volly_gpu_scene {
+    int device = 0;
+    bool is_svo = false, has_low = false;
+    bool refill = false;            // incoherent dense scene: use the ray-refill frame kernel
+    vk::DenseDev target{}, low{};
+    vk::SvoDev svo{};
+    uint32_t n_leaves = 0;
+    // owned device allocations
+    std::vector<void *> owned;
+    size_t bytes = 0;
+    // per-call scratch
+    volly_frame_desc *d_frames = nullptr;
+    float *d_ckpt = nullptr;
+    size_t ckpt_floats = 0;
+    void *d_planes = nullptr;       // staging of the synchronous entry point
+    size_t plane_bytes = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+namespace vimpl {
+
+int new_scene(int device, volly_gpu_scene **out);
+void destroy(volly_gpu_scene *s);
+int dev_alloc(volly_gpu_scene *s, void **p, size_t bytes);
+// hand an existing device allocation over to the scene (freed with it)
+void adopt(volly_gpu_scene *s, void *p, size_t bytes);
+// upload (host_vox) or adopt (dev_vox, already owned by the scene) the 8-byte voxels of one grid and derive its occupancy levels
+int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox, uint2 *dev_vox, vk::DenseDev *out);
+// describe a device-resident octree (arrays already owned by the scene) and build its direct-index table
+int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res);
+void choose_frame_kernel(volly_gpu_scene *s);
+
+} // namespace vimpl
+
+#endif

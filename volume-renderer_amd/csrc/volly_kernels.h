@@ -106,6 +106,8 @@ struct OutDev {
     float *depth;
 };
 
+#ifndef VOLLY_TYPES_ONLY            // (the other translation units of the library need only the types above)
+
 struct Ray {
     float dx, dy, dz;               // direction
     float ix, iy, iz;               // 1/direction
@@ -814,6 +816,8 @@ __global__ void __launch_bounds__(256) reduce_low(const uint64_t *occ_hi, int nb
     if (b >= nb) return;
     vox_lo[b] = occ_hi[b] ? make_uint2(0xFFFFFFFFu, 0u) : make_uint2(0u, 0u);
 }
+
+#endif // VOLLY_TYPES_ONLY
 
 } // namespace vk
 #endif

@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from ._abi import (LIB_DIR, DenseDesc, SvoDesc, FrameDesc, Outputs, PLANES, VOLLY_OK)
+from ._abi import (LIB_DIR, DenseDesc, SvoDesc, FrameDesc, MeshDesc, Outputs, PLANES, VOLLY_OK, VOX_DENSE, VOX_SVO)
 
 try:
     # torch ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
@@ -30,11 +30,14 @@ _sig = {
     "volume_gpu_upload": (C.c_int, [C.c_int, C.POINTER(DenseDesc), C.POINTER(DenseDesc), C.POINTER(_vp)]),
     "svo_gpu_upload": (C.c_int, [C.c_int, C.POINTER(SvoDesc), C.POINTER(DenseDesc), C.POINTER(_vp)]),
     "volume_gpu_generate_noise": (C.c_int, [C.c_int, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
+    "volume_gpu_voxelize": (C.c_int, [C.c_int, C.POINTER(MeshDesc), C.c_int32, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "volume_gpu_render": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs)]),
     "volume_gpu_render_device": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs), _vp]),
     "volly_gpu_set_profiling": (C.c_int, [_vp, C.c_int]),
     "volly_gpu_kernel_time": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "volly_gpu_read_voxels": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
+    "volly_gpu_read_low_voxels": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
+    "volly_gpu_read_svo": (C.c_int, [_vp, _vp, _vp]),
     "volly_gpu_scene_info": (C.c_int64, [_vp, C.c_int]),
     "volly_gpu_free": (None, [_vp]),
     "volly_gpu_last_error": (C.c_char_p, []),
@@ -101,6 +104,18 @@ class GpuScene:
         _check(lib.volume_gpu_generate_noise(device, res, seed, threshold, C.byref(h)), "volume_gpu_generate_noise")
         return cls(h)
 
+    @classmethod
+    def voxelize(cls, mesh, res, dense=False, svo=True, device=0):
+        """volume_gpu_voxelize: `mesh` is a MeshDesc (host.HostMesh(...).desc).  Returns the scene;
+        its .vox_stats holds the call's statistics."""
+        h = _vp()
+        stats = (C.c_int64 * 8)()
+        flags = (VOX_DENSE if dense else 0) | (VOX_SVO if svo else 0)
+        _check(lib.volume_gpu_voxelize(device, C.byref(mesh), res, flags, C.byref(h), stats), "volume_gpu_voxelize")
+        out = cls(h)
+        out.vox_stats = dict(zip(("triangles", "tests", "pairs", "levels", "cells", "microseconds", "scratch_bytes"), list(stats)))
+        return out
+
     def info(self, what):
         return int(lib.volly_gpu_scene_info(self._h, what))
 
@@ -140,6 +155,20 @@ class GpuScene:
         out = np.empty((count, 8), np.uint8)
         _check(lib.volly_gpu_read_voxels(self._h, first, count, out.ctypes.data), "volly_gpu_read_voxels")
         return out
+
+    def read_low_voxels(self):
+        n = self.info(5) ** 3
+        out = np.empty((n, 8), np.uint8)
+        _check(lib.volly_gpu_read_low_voxels(self._h, 0, n, out.ctypes.data), "volly_gpu_read_low_voxels")
+        return out
+
+    def read_svo(self):
+        """(nodes structured array, leaves (n, 8) uint8) copied back from the device."""
+        dt = np.dtype([("child_offset", "<u4"), ("valid_mask", "u1"), ("leaf_mask", "u1"), ("pad", "<u2")])
+        nodes = np.empty(self.info(10), dt)
+        leaves = np.empty((self.info(11), 8), np.uint8)
+        _check(lib.volly_gpu_read_svo(self._h, nodes.ctypes.data, leaves.ctypes.data), "volly_gpu_read_svo")
+        return nodes, leaves
 
     def close(self):
         if self._h:

@@ -5,7 +5,7 @@ import os
 
 import numpy as np
 
-from ._abi import (LIB_DIR, DenseDesc, SvoDesc, SvoNode, FrameDesc, SCENE_DENSE, SCENE_SVO, VOLLY_OK,
+from ._abi import (LIB_DIR, DenseDesc, SvoDesc, SvoNode, FrameDesc, MeshDesc, SCENE_DENSE, SCENE_SVO, VOLLY_OK,
                    VOLLY_E_UNSUPPORTED)
 
 _path = os.path.join(LIB_DIR, "libvolly_host.so")
@@ -27,6 +27,9 @@ _sig = {
     "volly_host_scene_free": (None, [_vp]),
     "volly_host_scene_save": (C.c_int, [_vp, C.c_char_p]),
     "volly_host_scene_load": (_vp, [C.c_char_p]),
+    "volly_host_mesh_load": (_vp, [C.c_char_p, _i32]),
+    "volly_host_mesh_view": (C.c_int, [_vp, C.POINTER(MeshDesc)]),
+    "volly_host_mesh_free": (None, [_vp]),
     "volly_host_lod_set_load": (_vp, [C.c_char_p, _i32, _i32, _i32, _i32]),
     "volly_host_lod_set_grid": (C.c_int, [_vp, _i32, C.POINTER(DenseDesc)]),
     "volly_host_lod_set_free": (None, [_vp]),
@@ -141,6 +144,29 @@ class HostScene:
     def close(self):
         if self._h:
             lib.volly_host_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostMesh:
+    """A mesh read and normalised the way rasterizeVoxelMapFromPoly sees it (volly_host_mesh_load)."""
+
+    def __init__(self, path, n_normalize=2):
+        self._h = lib.volly_host_mesh_load(os.fsencode(path), n_normalize)
+        if not self._h:
+            raise RuntimeError("host mesh: " + _err())
+        self.desc = MeshDesc()
+        if lib.volly_host_mesh_view(self._h, C.byref(self.desc)) != VOLLY_OK:
+            raise RuntimeError("host mesh: descriptor")
+
+    def close(self):
+        if self._h:
+            lib.volly_host_mesh_free(self._h)
             self._h = None
 
     def __del__(self):

@@ -20,6 +20,11 @@ struct volly_host_lod_set {
     std::unique_ptr<Vol_LOD_Set> set;
 };
 
+struct volly_host_mesh {
+    std::unique_ptr<Polyhedron> poly;
+};
+static_assert(sizeof(vec4) == 16 && sizeof(ivec3) == 12, "mesh arrays are handed out as plain float / int32 arrays");
+
 namespace {
 thread_local std::string g_err;
 
@@ -68,6 +73,34 @@ volly_host_scene *volly_host_scene_from_mesh(const char *path, int32_t res, int3
     if (flags & VOLLY_SCENE_SVO) s->svo = std::make_unique<SparseVoxelOctree>(s->map.get(), res);
     return s.release();
 }
+
+volly_host_mesh *volly_host_mesh_load(const char *path, int32_t n_normalize)
+{
+    g_err.clear();
+    if (!path || n_normalize < 0) { g_err = "volly_host_mesh_load: bad arguments"; return nullptr; }
+    std::string err;
+    std::unique_ptr<Polyhedron> poly(readMeshFile(path, &err));
+    if (!err.empty() || poly->verts.empty() || poly->inds.empty()) {
+        g_err = err.empty() ? std::string("empty mesh: ") + path : err;
+        return nullptr;
+    }
+    for (int i = 0; i < n_normalize; ++i) normalizePoly(poly.get());
+    auto m = std::make_unique<volly_host_mesh>();
+    m->poly = std::move(poly);
+    return m.release();
+}
+
+int volly_host_mesh_view(const volly_host_mesh *m, volly_mesh_desc *out)
+{
+    if (!m || !out) return VOLLY_E_ARG;
+    out->n_verts = (int64_t)m->poly->verts.size();
+    out->verts = &m->poly->verts[0].x;
+    out->n_tris = (int64_t)m->poly->inds.size();
+    out->tris = &m->poly->inds[0].x;
+    return VOLLY_OK;
+}
+
+void volly_host_mesh_free(volly_host_mesh *m) { delete m; }
 
 volly_host_scene *volly_host_scene_sphere(int32_t res, const uint8_t fill[8], int32_t flags)
 {
