@@ -286,6 +286,19 @@ vox_seed(const TriRec *rec, const uint64_t *bitoff, int n_tris, uint32_t *seen, 
     }
 }
 
+// exclusive prefix sum over the lanes of a wavefront; total = sum over all lanes
+__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t &total)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += t;
+    }
+    total = (uint32_t)__shfl((int)incl, 63);
+    return incl - v;
+}
+
 // One search level: test every (triangle, cell) of the frontier; a passing cell is recorded and
 // its 26 neighbours not yet seen by this triangle form the next frontier
 // (PLYfileReader.cpp:250-275).  counters: [0] next frontier size, [1] queue overflow,
@@ -322,52 +335,74 @@ vox_level(const TriRec *rec, const uint64_t *bitoff, const uint64_t *in, uint32_
         const uint64_t m = __ballot(have);
         if (lane == 0 && m) atomicAdd(tests, (unsigned long long)__popcll(m));
     }
-    for (int d = 0; d < 27; ++d) {
-        if (d == 13) continue;
-        const int dx = d % 3 - 1, dy = (d / 3) % 3 - 1, dz = d / 9 - 1;
-        bool push = false;
-        uint64_t item = 0;
-        if (passed) {
-            const int qx = x + dx, qy = y + dy, qz = z + dz;
-            // cells outside [-2, res+1] cannot touch a mesh that lies in [0, res-1]^3
-            if (qx >= -2 && qy >= -2 && qz >= -2 && qx <= res + 1 && qy <= res + 1 && qz <= res + 1) {
-                const int lx = qx - ox, ly = qy - oy, lz = qz - oz;
-                if (lx < 0 || ly < 0 || lz < 0 || lx >= nx || ly >= ny || lz >= nz) {
-                    atomicAdd(&counters[2], 1u);
-                } else {
-                    const uint64_t bit = base + (uint64_t)lx + (uint64_t)nx * ((uint64_t)ly + (uint64_t)ny * (uint64_t)lz);
-                    const uint32_t m = 1u << (bit & 31);
-                    push = !(atomicOr(&seen[bit >> 5], m) & m);
-                    item = vox_item(tri, qx, qy, qz);
-                }
+    // The 26 neighbours, one row of three (dx = -1, 0, 1) at a time: the three "seen" bits of a
+    // row are adjacent, so a row costs one read and, only if a bit looks clear, one atomic OR
+    // (two when the row straddles a word).  The read may be stale -- bits are only ever set, so
+    // a stale word can only send a cell to the atomic that did not need it.  Device-scope
+    // atomics are the expensive operation here (they complete beyond the per-XCD L2).
+    uint32_t fresh = 0;                                   // bit 3 * row + (dx + 1): first seen now
+    if (passed) {
+        #pragma unroll
+        for (int row = 0; row < 9; ++row) {
+            const int dy = row % 3 - 1, dz = row / 3 - 1;
+            const int qy = y + dy, qz = z + dz;
+            if (qy < -2 || qz < -2 || qy > res + 1 || qz > res + 1) continue;
+            const int ly = qy - oy, lz = qz - oz;
+            uint32_t want = 0;                            // which of the three cells to look at
+            #pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int qx = x + k - 1;
+                if (row == 4 && k == 1) continue;         // the cell itself
+                if (qx < -2 || qx > res + 1) continue;
+                want |= 1u << k;
             }
-        }
-        const uint64_t m = __ballot(push);
-        if (m) {                                          // one counter update per wavefront
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t first = 0;
-            if (lane == leader) first = atomicAdd(&counters[0], (uint32_t)__popcll(m));
-            first = (uint32_t)__shfl((int)first, leader);
-            if (push) {
-                const uint32_t pos = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < cap) out[pos] = item;
-                else counters[1] = 1u;
+            if (!want) continue;
+            const int lx0 = x - 1 - ox;
+            const bool row_in_box = ly >= 0 && lz >= 0 && ly < ny && lz < nz;
+            uint32_t in_box = 0;
+            #pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (row_in_box && lx0 + k >= 0 && lx0 + k < nx) in_box |= 1u << k;
+            if (want & ~in_box) atomicAdd(&counters[2], 1u);
+            want &= in_box;
+            if (!want) continue;
+            // bit of cell lx0 (may be "before" the box when lx0 == -1: then bit 0 of want is clear)
+            const int64_t bit0 = (int64_t)base + (int64_t)lx0 + (int64_t)nx * ((int64_t)ly + (int64_t)ny * (int64_t)lz);
+            const int64_t w0 = bit0 >> 5;                 // arithmetic shift: floor
+            const uint32_t sh = (uint32_t)(bit0 & 31);
+            const uint64_t m64 = (uint64_t)want << sh;
+            const uint32_t m_lo = (uint32_t)m64, m_hi = (uint32_t)(m64 >> 32);
+            uint32_t got = 0;                             // bits of want that were clear before our OR
+            if (m_lo) {
+                uint32_t cur = seen[w0];
+                if (~cur & m_lo) cur = atomicOr(&seen[w0], m_lo);
+                got |= (uint32_t)(((uint64_t)(~cur & m_lo)) >> sh);
             }
+            if (m_hi) {
+                uint32_t cur = seen[w0 + 1];
+                if (~cur & m_hi) cur = atomicOr(&seen[w0 + 1], m_hi);
+                got |= (uint32_t)((((uint64_t)(~cur & m_hi)) << 32) >> sh);
+            }
+            fresh |= (got & 7u) << (3 * row);
         }
     }
-}
-
-// exclusive prefix sum over the lanes of a wavefront; total = sum over all lanes
-__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t &total)
-{
-    const int lane = (int)(threadIdx.x & 63);
-    uint32_t incl = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += t;
+    // next frontier: one counter update per wavefront
+    const uint32_t mine = (uint32_t)__popc(fresh);
+    uint32_t total;
+    const uint32_t before = wave_exclusive_scan(mine, total);
+    if (total) {
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(&counters[0], total);
+        first = (uint32_t)__shfl((int)first, 0);
+        uint32_t pos = first + before;
+        for (uint32_t f = fresh; f; f &= f - 1) {
+            const int k = __ffs((int)f) - 1;
+            const int row = k / 3, dx = k % 3 - 1, dy = row % 3 - 1, dz = row / 3 - 1;
+            if (pos < cap) out[pos] = vox_item(tri, x + dx, y + dy, z + dz);
+            else counters[1] = 1u;
+            ++pos;
+        }
     }
-    total = (uint32_t)__shfl((int)incl, 63);
-    return incl - v;
 }
 
 __device__ __forceinline__ uint64_t vox_word(int x, int y, int z, uint32_t tri)
