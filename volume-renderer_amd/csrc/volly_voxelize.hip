@@ -302,7 +302,7 @@ __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t &to
 // One search level: test every (triangle, cell) of the frontier; a passing cell is recorded and
 // its 26 neighbours not yet seen by this triangle form the next frontier
 // (PLYfileReader.cpp:250-275).  counters: [0] next frontier size, [1] queue overflow,
-// [2] cells outside a triangle's box; tests: number of cube tests run.
+// [2] cells outside a triangle's box; tests: [0] cube tests run, [1] passing cells with x > 1.
 __global__ void __launch_bounds__(256)
 vox_level(const TriRec *rec, const uint64_t *bitoff, const uint64_t *in, uint32_t n_in, uint64_t *out, uint32_t cap, uint32_t *seen,
           uint32_t *pass, int res, uint32_t *counters, unsigned long long *tests)
@@ -333,7 +333,9 @@ vox_level(const TriRec *rec, const uint64_t *bitoff, const uint64_t *in, uint32_
     }
     {
         const uint64_t m = __ballot(have);
-        if (lane == 0 && m) atomicAdd(tests, (unsigned long long)__popcll(m));
+        if (lane == 0 && m) atomicAdd(&tests[0], (unsigned long long)__popcll(m));
+        const uint64_t k = __ballot(passed && x > 1);     // pairs vox_emit will write (PLYfileReader.cpp:278)
+        if (lane == 0 && k) atomicAdd(&tests[1], (unsigned long long)__popcll(k));
     }
     // The 26 neighbours, one row of three (dx = -1, 0, 1) at a time: the three "seen" bits of a
     // row are adjacent, so a row costs one read and, only if a bit looks clear, one atomic OR
@@ -425,11 +427,12 @@ __device__ __forceinline__ void vox_unword(uint64_t w, int &x, int &y, int &z, u
 // found by bisection of the box offsets.
 __global__ void __launch_bounds__(256)
 vox_emit(const TriRec *rec, const uint64_t *bitoff, int n_tris, const uint32_t *pass, uint64_t n_words, uint64_t *out,
-         unsigned long long *count)
+         uint64_t out_cap, unsigned long long *count)
 {
     for (uint64_t first = (uint64_t)blockIdx.x * blockDim.x; first < n_words; first += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t w = first + threadIdx.x;
         uint32_t bits = w < n_words ? pass[w] : 0u;
+        if (!__ballot(bits != 0u)) continue;              // most of a box is empty space
         uint32_t tri = 0;
         int ox = 0, oy = 0, oz = 0, nx = 1, ny = 1;
         uint64_t local0 = 0;
@@ -469,7 +472,8 @@ vox_emit(const TriRec *rec, const uint64_t *bitoff, int n_tris, const uint32_t *
                 const int x = ox + (int)(l % (uint64_t)nx);
                 const int y = oy + (int)((l / (uint64_t)nx) % (uint64_t)ny);
                 const int z = oz + (int)(l / ((uint64_t)nx * (uint64_t)ny));
-                out[o++] = vox_word(x, y, z, tri);
+                if (o < out_cap) out[o] = vox_word(x, y, z, tri);
+                ++o;
             }
         }
     }
@@ -805,10 +809,10 @@ int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags
     const uint32_t cap = (uint32_t)cap64;
     DevBuf q0, q1, counters, tests;
     HIP_TRY(q0.alloc((size_t)cap * 8)); HIP_TRY(q1.alloc((size_t)cap * 8));
-    HIP_TRY(counters.alloc(16)); HIP_TRY(tests.alloc(8));
+    HIP_TRY(counters.alloc(16)); HIP_TRY(tests.alloc(16));
     sc.add((size_t)cap * 16);
     HIP_TRY(hipMemset(counters.p, 0, 16));
-    HIP_TRY(hipMemset(tests.p, 0, 8));
+    HIP_TRY(hipMemset(tests.p, 0, 16));
     hipLaunchKernelGGL(vk::vox_seed, dim3(blocks_for((uint64_t)n_tris)), dim3(256), 0, 0, d_rec.as<vk::TriRec>(), d_off.as<uint64_t>(), n_tris,
                        seen.as<uint32_t>(), q0.as<uint64_t>(), counters.as<uint32_t>());
     HIP_TRY(hipGetLastError());
@@ -832,8 +836,9 @@ int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags
         ++levels;
     }
     if (hc[2]) return fail(VOLLY_E_HIP, "volume_gpu_voxelize: internal error, a search left its triangle's box");
-    unsigned long long n_tests = 0;
-    HIP_TRY(hipMemcpy(&n_tests, tests.p, 8, hipMemcpyDeviceToHost));
+    unsigned long long h_tests[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h_tests, tests.p, 16, hipMemcpyDeviceToHost));
+    const unsigned long long n_tests = h_tests[0];
     q0.reset(); q1.reset(); seen.reset();
     sc.sub((size_t)cap * 16 + n_bitwords * 4);
 
@@ -842,22 +847,18 @@ int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags
     HIP_TRY(n_hits.alloc(8));
     HIP_TRY(hipMemset(n_hits.p, 0, 8));
     const unsigned emit_blocks = (unsigned)std::min<uint64_t>((n_bitwords + 255) / 256, 1u << 16);
-    if (n_bitwords) {
-        hipLaunchKernelGGL(vk::vox_emit, dim3(emit_blocks), dim3(256), 0, 0, d_rec.as<vk::TriRec>(), d_off.as<uint64_t>(), n_tris,
-                           pass.as<uint32_t>(), n_bitwords, (uint64_t *)nullptr, n_hits.as<unsigned long long>());
-        HIP_TRY(hipGetLastError());
-    }
-    unsigned long long hits = 0;
-    HIP_TRY(hipMemcpy(&hits, n_hits.p, 8, hipMemcpyDeviceToHost));
+    const unsigned long long hits = h_tests[1];          // counted by the search itself
     DevBuf wa, wb;
     HIP_TRY(wa.alloc((size_t)hits * 8)); HIP_TRY(wb.alloc((size_t)hits * 8));
     sc.add((size_t)hits * 16);
     if (hits) {
         HIP_TRY(hipMemset(n_hits.p, 0, 8));
         hipLaunchKernelGGL(vk::vox_emit, dim3(emit_blocks), dim3(256), 0, 0, d_rec.as<vk::TriRec>(), d_off.as<uint64_t>(), n_tris,
-                           pass.as<uint32_t>(), n_bitwords, wa.as<uint64_t>(), n_hits.as<unsigned long long>());
+                           pass.as<uint32_t>(), n_bitwords, wa.as<uint64_t>(), (uint64_t)hits, n_hits.as<unsigned long long>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipDeviceSynchronize());
+        unsigned long long written = 0;
+        HIP_TRY(hipMemcpy(&written, n_hits.p, 8, hipMemcpyDeviceToHost));
+        if (written != hits) return fail(VOLLY_E_HIP, "volume_gpu_voxelize: internal error, pair count mismatch");
     }
     pass.reset();
     sc.sub(n_bitwords * 4);
