@@ -137,6 +137,14 @@ int volume_gpu_generate_noise(int device, int32_t res, uint32_t seed, uint32_t t
 int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames,
                       const volly_outputs *outs);
 
+/* Page-locked host memory for the output planes of volume_gpu_render (the role of the
+ * SDL streaming texture the reference locks at main.cpp:199 and unlocks at :290).  When
+ * every requested plane lies in such memory (or in memory pinned by hipHostMalloc /
+ * hipHostRegister) the call renders in batches and copies each batch back while the next
+ * one is traversed; pageable memory works too, through the runtime's staged copy. */
+void *volly_gpu_host_alloc(size_t bytes);
+void  volly_gpu_host_free(void *p);
+
 /* Same, planes in `outs` are DEVICE pointers on the scene's GPU; work is queued
  * on `hip_stream` (a hipStream_t, NULL = default stream) and the call returns
  * without waiting.  `frames` is consumed before the call returns. */

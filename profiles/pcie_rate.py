@@ -17,3 +17,15 @@ for planes in (("rgba8",), ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth
         gpu.render(frames, planes=planes)
     dt = (time.perf_counter() - t) / 5
     print(f"{len(planes)} plane(s) to pageable host memory: {16 * 1920 * 1080 / dt / 1e6:.0f} Mrays/s ({dt * 1e3:.1f} ms per 16 views)")
+    pins = {q: vra.gpu.PinnedArray((16, 1080, 1920), "float32" if q == "depth" else "uint32") for q in planes}
+    arrays = {q: a.array for q, a in pins.items()}
+    gpu.render_into(frames, arrays)
+    ref = gpu.render(frames, planes=planes)
+    same = all((arrays[q].view("uint32") == ref[q].view("uint32")).all() for q in planes)
+    t = time.perf_counter()
+    for _ in range(5):
+        gpu.render_into(frames, arrays)
+    dt = (time.perf_counter() - t) / 5
+    print(f"{len(planes)} plane(s) to pinned host memory:   {16 * 1920 * 1080 / dt / 1e6:.0f} Mrays/s ({dt * 1e3:.1f} ms per 16 views), equal to the pageable result: {same}")
+    for a in pins.values():
+        a.close()

@@ -346,3 +346,29 @@ def test_short_division_sequences_are_exact():
     assert bad["rcp_a"] == 0 and bad["sqrt_candidates"] == 0, r.stdout
     m = re.search(r"n/255 refined: (\d+) mismatches", r.stdout)
     assert m and int(m.group(1)) == 0, r.stdout
+
+
+def test_pinned_output_buffers_take_the_overlapped_path_and_agree(vra, ora):
+    """volume_gpu_render into page-locked buffers (volly_gpu_host_alloc) renders in batches and
+    copies back on a second stream; the planes must equal the pageable path's, for a call that
+    spans several batches and an odd frame size."""
+    host = vra.HostScene.from_mesh(os.path.join(ASSETS, "teapot.off"), 128, dense=True, svo=False)
+    gpu = vra.GpuScene.upload_dense(host.target, host.low)
+    n, w, h = 37, 333, 251
+    frames = vra.orbit_frames(range(0, 37 * 100, 100), 4096, (128,) * 3, (32,) * 3, w, h)
+    ref = gpu.render(frames)
+    pins = {p: vra.gpu.PinnedArray((n, h, w), np.float32 if p == "depth" else np.uint32) for p in ref}
+    for a in pins.values():
+        a.array.view(np.uint32)[...] = 0xDEADBEEF
+    gpu.render_into(frames, {p: a.array for p, a in pins.items()})
+    for p in ref:
+        assert np.array_equal(pins[p].array.view(np.uint32), ref[p].view(np.uint32)), p
+    # a subset of planes, half of them pinned: falls back to the plain path, same result
+    mixed = {"rgba8": pins["rgba8"].array, "depth": np.empty((n, h, w), np.float32)}
+    mixed["rgba8"][...] = 0
+    gpu.render_into(frames, mixed)
+    assert np.array_equal(mixed["rgba8"], ref["rgba8"]) and np.array_equal(mixed["depth"].view(np.uint32), ref["depth"].view(np.uint32))
+    for a in pins.values():
+        a.close()
+    gpu.close()
+    host.close()

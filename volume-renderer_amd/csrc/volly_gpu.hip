@@ -111,6 +111,8 @@ void destroy(volly_gpu_scene *s)
     if (s->d_frames) (void)hipFree(s->d_frames);
     if (s->d_ckpt) (void)hipFree(s->d_ckpt);
     if (s->d_planes) (void)hipFree(s->d_planes);
+    if (s->s_render) (void)hipStreamDestroy(s->s_render);
+    if (s->s_copy) (void)hipStreamDestroy(s->s_copy);
     delete s;
 }
 
@@ -406,11 +408,71 @@ int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, in
     for (int i = 0; i < 5; ++i)
         if (host[i]) dev[i] = (uint32_t *)scene->d_planes + (k++) * px;
     volly_outputs d{dev[0], dev[1], dev[2], dev[3], (float *)dev[4]};
+
+    // Output buffers in pinned host memory (volly_gpu_host_alloc, hipHostMalloc, hipHostRegister):
+    // render a few frames at a time on one stream and copy each batch back on another, so the
+    // PCIe transfer of batch k overlaps the traversal of batch k+1.  Pageable buffers take the
+    // plain path below (the runtime stages them through its own pinned buffers).
+    bool pinned = wanted > 0;
+    for (void *h : host) {
+        if (!h) continue;
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, h) != hipSuccess || a.type != hipMemoryTypeHost) { pinned = false; (void)hipGetLastError(); }
+    }
+    if (pinned) {
+        if (!scene->s_render) HIP_TRY(hipStreamCreateWithFlags(&scene->s_render, hipStreamNonBlocking));
+        if (!scene->s_copy) HIP_TRY(hipStreamCreateWithFlags(&scene->s_copy, hipStreamNonBlocking));
+        const size_t fpx = (size_t)frames[0].tile_w * frames[0].tile_h;
+        const int batch = (int)std::min<size_t>(std::max<size_t>((size_t)(4u << 20) / std::max<size_t>(fpx, 1), 1), (size_t)kFrameChunk);   // ~4 Mpixel per batch
+        std::vector<hipEvent_t> evs;
+        int status = VOLLY_OK;
+        for (int first = 0; first < n_frames && status == VOLLY_OK; first += batch) {
+            const int n = std::min(batch, n_frames - first);
+            status = render_chunk(scene, frames + first, n, (size_t)first, &d, scene->s_render);
+            if (status) break;
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, scene->s_render) != hipSuccess ||
+                hipStreamWaitEvent(scene->s_copy, ev, 0) != hipSuccess) {
+                status = fail(VOLLY_E_HIP, "render: event set-up failed");
+                if (ev) (void)hipEventDestroy(ev);
+                break;
+            }
+            evs.push_back(ev);
+            for (int i = 0; i < 5 && status == VOLLY_OK; ++i)
+                if (host[i] && hipMemcpyAsync((uint32_t *)host[i] + (size_t)first * fpx, dev[i] + (size_t)first * fpx, (size_t)n * fpx * 4,
+                                              hipMemcpyDeviceToHost, scene->s_copy) != hipSuccess)
+                    status = fail(VOLLY_E_HIP, "render: copy to pinned host memory failed");
+        }
+        // render_chunk reuses the frame-descriptor and checkpoint scratch: a batch must not start
+        // before the previous one has finished with them -- same stream, so it does not
+        hipError_t e1 = hipStreamSynchronize(scene->s_render), e2 = hipStreamSynchronize(scene->s_copy);
+        for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+        if (status) return status;
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(VOLLY_E_HIP, "render: stream synchronisation failed");
+        return VOLLY_OK;
+    }
+
     if ((rc = volume_gpu_render_device(scene, frames, n_frames, &d, nullptr))) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));
     for (int i = 0; i < 5; ++i)
         if (host[i]) HIP_TRY(hipMemcpy(host[i], dev[i], px * 4, hipMemcpyDeviceToHost));
     return VOLLY_OK;
+}
+
+void *volly_gpu_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(VOLLY_E_NOMEM, "volly_gpu_host_alloc: hipHostMalloc failed");
+        return nullptr;
+    }
+    return p;
+}
+
+void volly_gpu_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int volly_gpu_set_profiling(volly_gpu_scene *scene, int enabled)

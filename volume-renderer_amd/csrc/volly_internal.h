@@ -60,6 +60,7 @@ struct volly_gpu_scene {
     size_t ckpt_floats = 0;
     void *d_planes = nullptr;       // staging of the synchronous entry point
     size_t plane_bytes = 0;
+    hipStream_t s_render = nullptr, s_copy = nullptr;   // pinned-output path: render and copy-back overlap
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;

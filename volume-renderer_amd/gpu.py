@@ -33,6 +33,8 @@ _sig = {
     "volume_gpu_voxelize": (C.c_int, [C.c_int, C.POINTER(MeshDesc), C.c_int32, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "volume_gpu_render": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs)]),
     "volume_gpu_render_device": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs), _vp]),
+    "volly_gpu_host_alloc": (_vp, [C.c_size_t]),
+    "volly_gpu_host_free": (None, [_vp]),
     "volly_gpu_set_profiling": (C.c_int, [_vp, C.c_int]),
     "volly_gpu_kernel_time": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "volly_gpu_read_voxels": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
@@ -73,6 +75,30 @@ def _frames_array(frames):
     for i, f in enumerate(frames):
         arr[i] = f
     return arr, len(frames)
+
+
+class PinnedArray:
+    """numpy view over page-locked host memory (volly_gpu_host_alloc); keep the object alive
+    while `.array` is in use."""
+
+    def __init__(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib.volly_gpu_host_alloc(n)
+        if not self._p:
+            raise VollyError(-3, "volly_gpu_host_alloc")
+        self.array = np.frombuffer((C.c_uint8 * n).from_address(self._p), dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib.volly_gpu_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _DT = {"rgba8": np.uint32, "hit_index": np.uint32, "steps_lo": np.uint32, "steps_hi": np.uint32, "depth": np.float32}
@@ -136,6 +162,15 @@ class GpuScene:
         outs = Outputs(*[res[p].ctypes.data if p in res else None for p in PLANES])
         _check(lib.volume_gpu_render(self._h, arr, n, C.byref(outs)), "volume_gpu_render")
         return res
+
+    def render_into(self, frames, arrays):
+        """Synchronous render into caller-owned host arrays (dict plane -> C-contiguous array of
+        n_frames * tile_h * tile_w 4-byte elements), e.g. PinnedArray(...).array."""
+        arr, n = _frames_array(frames)
+        for p, a in arrays.items():
+            assert a.flags["C_CONTIGUOUS"] and a.size == n * arr[0].tile_h * arr[0].tile_w and a.itemsize == 4, p
+        outs = Outputs(*[arrays[p].ctypes.data if p in arrays else None for p in PLANES])
+        _check(lib.volume_gpu_render(self._h, arr, n, C.byref(outs)), "volume_gpu_render")
 
     def render_device(self, frames, ptrs, stream=None):
         """Asynchronous render into device memory.  ptrs: dict plane -> device pointer (int)."""
