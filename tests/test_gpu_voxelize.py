@@ -83,3 +83,58 @@ def test_argument_errors(vra):
     with pytest.raises(vra.VollyError):
         vra.GpuScene.voxelize(hm.desc, 8192)
     hm.close()
+
+
+def _write_off(path, verts, tris):
+    with open(path, "w") as f:
+        f.write(f"OFF\n{len(verts)} {len(tris)} 0\n")
+        for v in verts:
+            f.write("%r %r %r\n" % tuple(float(c) for c in v))
+        for t in tris:
+            f.write("3 %d %d %d\n" % tuple(t))
+
+
+def _compare_everything(vra, path, res):
+    host = vra.HostScene.from_mesh(path, res, dense=True, svo=True)
+    hm = vra.HostMesh(path, 2)
+    gpu = vra.GpuScene.voxelize(hm.desc, res, dense=True, svo=True)
+    want = vra.host.dense_view(host.target).reshape(-1, 8)
+    assert np.array_equal(gpu.read_voxels(0, res ** 3), want)
+    assert np.array_equal(gpu.read_low_voxels(), vra.host.dense_view(host.low).reshape(-1, 8))
+    nh, lh = host.svo_arrays()
+    ng, lg = gpu.read_svo()
+    assert np.array_equal(ng.view(np.uint64), nh.view(np.uint64)) and np.array_equal(lg, lh)
+    filled = int((want[:, 3] > 0).sum())
+    for s in (gpu, hm, host):
+        s.close()
+    return filled
+
+
+def test_ragged_meshes_equal_the_host(vra, tmp_path):
+    """Degenerate faces (repeated vertex: NaN normal -> 0 bytes), an index outside the vertex
+    list (skipped), slivers, a triangle spanning the whole grid, coincident triangles (the later
+    one owns the cell), random soup."""
+    rng = np.random.default_rng(5)
+    verts = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1), (0.3, 0.3, 0.3), (0.3001, 0.3, 0.3), (0.9, 0.1, 0.5)]
+    tris = [(0, 1, 2), (0, 1, 3), (0, 2, 3), (1, 2, 3),      # tetrahedron
+            (4, 4, 5),                                       # degenerate: two equal vertices
+            (0, 1, 99),                                      # vertex index out of range
+            (5, 6, 7),                                       # sliver
+            (0, 4, 7), (7, 4, 0),                            # same triangle twice, opposite winding: the later normal wins
+            (2, 3, 4)]
+    p = str(tmp_path / "ragged.off")
+    _write_off(p, verts, tris)
+    assert _compare_everything(vra, p, 64) > 500
+    soup_v = rng.random((300, 3))
+    soup_t = rng.integers(0, 300, (400, 3))
+    p2 = str(tmp_path / "soup.off")
+    _write_off(p2, soup_v, soup_t)
+    assert _compare_everything(vra, p2, 96) > 5000
+
+
+def test_flat_mesh_gives_the_same_empty_scene(vra, tmp_path):
+    """All vertices in one plane: normalizePoly divides by a zero extent (PLYfileReader.cpp:
+    160-168), the scaled vertices are not finite and no triangle is rasterised."""
+    p = str(tmp_path / "flat.off")
+    _write_off(p, [(0, 0, 0.5), (1, 0, 0.5), (0, 1, 0.5), (1, 1, 0.5)], [(0, 1, 2), (1, 3, 2)])
+    assert _compare_everything(vra, p, 32) == 0

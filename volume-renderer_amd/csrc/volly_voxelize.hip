@@ -745,8 +745,9 @@ int build_octree(volly_gpu_scene *s, const uint64_t *words, uint64_t n_words, in
     if (at >= 0x80000000ull) return fail(VOLLY_E_UNSUPPORTED, "volume_gpu_voxelize: more than 2^31 octree nodes");
     uint2 *nodes = nullptr;
     if ((rc = dev_alloc(s, (void **)&nodes, at * 8))) return rc;
-    if (empty) {
-        HIP_TRY(hipMemset(nodes, 0, 8));
+    if (empty) {                                          // host/svo.cpp: the bare root points just past itself
+        const uint2 root = make_uint2(depth == 1 ? 0u : 1u, 0u);
+        HIP_TRY(hipMemcpy(nodes, &root, 8, hipMemcpyHostToDevice));
     } else {
         for (int L = depth; L >= 1; --L) {
             const Level &lv = level[(size_t)L];
