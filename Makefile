@@ -54,9 +54,12 @@ oracle/_ref/libtricube_ref.so: oracle/tricube_ref_export.cpp $(REF)/triangleCube
 examples: examples/volly_headless
 
 # device-side exhaustive check of the short division / sqrt sequences the kernels use
-tools: tools/exhaustive_math
+tools: tools/exhaustive_math tools/valu_rate
 tools/exhaustive_math: tools/exhaustive_math.hip
 	$(HIPCC) --offload-arch=gfx950 -O3 $(FPFLAGS) -Wno-unused-result -o $@ $<
+# issue rate of the instruction kinds the DDA loop is made of
+tools/valu_rate: tools/valu_rate.hip
+	$(HIPCC) --offload-arch=gfx950 -O3 -Wno-unused-result -o $@ $<
 
 # alternative builds of the kernels for A/B measurement (profiles/ab_bench.py); never loaded by the product
 VARDIR := $(LIBDIR)/variants
@@ -73,6 +76,6 @@ examples/volly_headless: examples/volly_headless.cpp $(PKG)/host/volly_state.h $
 	    -L$(LIBDIR) -lvolly_host -lvolly_gpu -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath-link,/opt/rocm/lib
 
 clean:
-	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref examples/volly_headless tools/exhaustive_math
+	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref examples/volly_headless tools/exhaustive_math tools/valu_rate
 
 .PHONY: all gpu host oracle ref examples tools variants clean
