@@ -252,6 +252,45 @@ def test_config2_dragon512_full_frame(vra, ora):
     gpu.close()
 
 
+def test_config5_stratocaster1024_full_frame_from_a_device_built_scene(vra, ora):
+    """BASELINE config 5: stratocaster.ply at 1024^3 (octree), 1920x1080 orbit views.  The GPU
+    scene is built on the device (volume_gpu_voxelize); the oracle traverses the host pipeline's
+    octree and low grid, so one comparison covers scene preparation and traversal."""
+    path = os.path.join(ASSETS, "stratocaster.ply")
+    scene = vra.HostScene.from_mesh(path, 1024, dense=False, svo=True)
+    mesh = vra.HostMesh(path, 2)
+    gpu = vra.GpuScene.voxelize(mesh.desc, 1024, dense=False, svo=True)
+    frames = vra.orbit_frames((100, 2200), 4096, (1024,) * 3, (256,) * 3, 1920, 1080, radius=1.2)
+    got = gpu.render(frames)
+    for i, f in enumerate(frames):
+        want = ora.render_frame(f, low=scene.low, svo=scene.svo, threads=16)
+        assert (want["hit_index"] != MISS).sum() > 20000
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"stratocaster1024 view {i}")
+    for s_ in (gpu, mesh, scene):
+        s_.close()
+
+
+def test_config4_galleon2048_row_bands_of_an_8k_frame(vra, ora):
+    """BASELINE config 4: galleon.ply at 2048^3 (octree only; hit_index is taken mod 2^32 there),
+    one 7680x4320 frame split into row bands.  Two bands of 64 rows, rendered as sub-rectangles
+    the way one GPU of eight would, equal the oracle's rows of the full frame."""
+    path = os.path.join(ASSETS, "galleon.ply")
+    scene = vra.HostScene.from_mesh(path, 2048, dense=False, svo=True)
+    mesh = vra.HostMesh(path, 2)
+    gpu = vra.GpuScene.voxelize(mesh.desc, 2048, dense=False, svo=True)
+    full = vra.orbit_frames((300,), 4096, (2048,) * 3, (512,) * 3, 7680, 4320, radius=1.0)[0]
+    hits = 0
+    for y0 in (1500, 2160):
+        band = full.band(y0, 64)
+        got = gpu.render(band)
+        want = ora.render_frame(band, low=scene.low, svo=scene.svo, threads=16)
+        hits += int((want["hit_index"] != MISS).sum())
+        assert_planes_equal({k: v[0] for k, v in got.items()}, want, f"galleon2048 rows {y0}..{y0 + 63}")
+    assert hits > 10000
+    for s_ in (gpu, mesh, scene):
+        s_.close()
+
+
 def test_reference_style_state_example(vra, ora, tmp_path):
     """examples/volly_headless: the reference's main loop on volly::State (C++ adapter over
     the C-ABI): galleon.ply, the default 16/32/128/256 LoD set, 400x300 target (main.h:112).
