@@ -252,6 +252,31 @@ def test_config2_dragon512_full_frame(vra, ora):
     gpu.close()
 
 
+def test_config3_noise1024_rays_of_the_4k_frame(vra, ora):
+    """BASELINE config 3: the device-generated 1024^3 noise volume (8 GiB of voxels) and its
+    256^3 low grid, 3840x2160.  The volume is read back and the oracle traces two 256x144
+    sub-rectangles of the 4K frame on it, beam and naive; the generator itself is pinned to the
+    host hash by test_noise_scene_matches_host_hash."""
+    res = 1024
+    gpu = vra.GpuScene.noise(res, 1, 1 << 24)
+    assert gpu.info(9) == 0
+    vox = gpu.read_voxels(0, res ** 3).reshape(res, res, res, 8)
+    low = gpu.read_low_voxels().reshape(res // 4, res // 4, res // 4, 8)
+    filled = int((vox[::8, ::8, ::8, 3] > 0).sum())
+    assert 0.5 < filled / (128 ** 3 / 256.0) < 2.0        # p = 2^24 / 2^32
+    t_desc, l_desc = vra.host.dense_desc(vox), vra.host.dense_desc(low)
+    for naive in (False, True):
+        full = vra.orbit_frames((700,), 4096, (res,) * 3, (res // 4,) * 3, 3840, 2160, radius=1.1, naive=naive)[0]
+        for x0, y0 in ((1800, 1000), (2500, 600)):
+            f = full.copy()
+            f.x0, f.y0, f.tile_w, f.tile_h = x0, y0, 256, 144
+            want = ora.render_frame(f, low=l_desc, target=t_desc, threads=16)
+            got = gpu.render(f)
+            assert_planes_equal({k: v[0] for k, v in got.items()}, want, f"noise1024 naive={naive} at {x0},{y0}")
+            assert (want["steps_hi"] > 0).sum() > 1000 and (want["hit_index"] != MISS).sum() > 1000
+    gpu.close()
+
+
 def test_config5_stratocaster1024_full_frame_from_a_device_built_scene(vra, ora):
     """BASELINE config 5: stratocaster.ply at 1024^3 (octree), 1920x1080 orbit views.  The GPU
     scene is built on the device (volume_gpu_voxelize); the oracle traverses the host pipeline's
