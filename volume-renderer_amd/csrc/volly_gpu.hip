@@ -199,8 +199,9 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
                  hipStream_t stream)
 {
     const int tw = frames[0].tile_w, th = frames[0].tile_h;
-    const int groups = (tw + vk::kTile - 1) / vk::kTile;
+    const int groups = (tw + vk::kCkpt - 1) / vk::kCkpt;
     const size_t need = (size_t)n * groups * th * 6;
+    if (need >= (1ull << 31)) return fail(VOLLY_E_ARG, "render: sub-rectangles of more than ~2^30 pixels per launch");
     if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, sizeof(volly_frame_desc) * kFrameChunk));
     if (need > s->ckpt_floats) {
         if (s->d_ckpt) { HIP_TRY(hipFree(s->d_ckpt)); s->d_ckpt = nullptr; s->ckpt_floats = 0; }
@@ -231,7 +232,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     bool any_raytrace = false;
     for (int i = 0; i < n; ++i) any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
     if (s->refill && !any_raytrace) {
-        const unsigned tiles = (unsigned)groups * (unsigned)((th + vk::kTile - 1) / vk::kTile);
+        const unsigned tiles = (unsigned)((tw + vk::kTile - 1) / vk::kTile) * (unsigned)((th + vk::kTile - 1) / vk::kTile);
         const unsigned waves = (tiles + vk::kRaysPerWave / 64 - 1) / (vk::kRaysPerWave / 64);
         hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
                            s->low, s->d_frames, s->d_ckpt, o);

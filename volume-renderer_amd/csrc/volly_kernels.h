@@ -34,6 +34,9 @@
 //   VK_LINEAR_TILE=1  a wavefront covers 64x1 pixels instead of 8x8
 //   VK_LDS_TOP=0      do not stage the top of the octree in LDS
 //   VK_XCD_REMAP=1    give each XCD (blockIdx % 8) one contiguous range of pixel blocks
+//   VK_CKPT_STRIDE=4  a direction checkpoint every 4 pixels instead of 8 (at most 3 instead of 7
+//                     serial adds per lane and component, twice the checkpoint traffic: measured
+//                     1.4 % slower on config 2, 4 % on config 1)
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
 //   VK_WAVE_BLOCK=0   four wavefronts (a 32x8 pixel block) per workgroup with the output rows
 //                     staged through LDS into 128-byte stores, instead of one wavefront per
@@ -66,12 +69,16 @@
 #ifndef VK_SHORT_DIV
 #define VK_SHORT_DIV 1
 #endif
+#ifndef VK_CKPT_STRIDE
+#define VK_CKPT_STRIDE 8
+#endif
 
 static_assert(!(VK_LINEAR_TILE && VK_WAVE_BLOCK), "the 32x2 wavefront tile needs the 32x8 workgroup (VK_WAVE_BLOCK=0)");
 
 namespace vk {
 
 constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
+constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pixels of a row (at most kCkpt - 1 adds per lane)
 constexpr int kBlockW = VK_WAVE_BLOCK ? 8 : 32;     // workgroup covers 8 x 8 (or 32 x 8) pixels
 constexpr int kBlockH = 8;
 constexpr int kThreads = 256;
@@ -568,7 +575,7 @@ __device__ V4 raytrace(const DenseDev &g, float sx, float sy, float sz, V4 dir, 
 // One thread per (frame, row of the sub-rectangle, component): the six components (target
 // xyz, low xyz) are independent chains of dependent adds, so each gets its own thread.
 // A thread walks its chain -- y adds down to its row, then along the row -- and stores the
-// running sum every kTile pixels.  ckpt layout: [frame][column group][component][row], so
+// running sum every kCkpt pixels.  ckpt layout: [frame][column group][component][row], so
 // the 64 rows of a workgroup store 256 contiguous bytes.
 __global__ void __launch_bounds__(64)
 direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames, float *__restrict__ ckpt)
@@ -592,13 +599,13 @@ direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames,
     }
     for (; i < y; ++i) v = v + dy;
     for (int x = 0; x < x0; ++x) v = v + dx;              // main.cpp:282-283, columns left of the sub-rectangle
-    const int groups = (tile_w + kTile - 1) / kTile;
+    const int groups = (tile_w + kCkpt - 1) / kCkpt;
     float *o = ckpt + ((size_t)f * (size_t)groups * 6 + (size_t)comp) * (size_t)tile_h + (size_t)yrel;
     const size_t stride = (size_t)tile_h * 6;
     for (int g = 0; g < groups; ++g) {
         o[(size_t)g * stride] = v;
         #pragma unroll
-        for (int i = 0; i < kTile; ++i) v = v + dx;
+        for (int i = 0; i < kCkpt; ++i) v = v + dx;
     }
 }
 
@@ -650,11 +657,12 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
     float o_depth = __uint_as_float(0x7F800000u);
 
     if (active) {
-        const int groups = (fd.tile_w + kTile - 1) / kTile;
-        const size_t cs = (size_t)fd.tile_h;
-        const float *c = ckpt + ((size_t)f * (size_t)groups + (size_t)(xrel / kTile)) * 6 * cs + (size_t)yrel;
+        // checkpoint scratch of one launch stays below 2^31 floats (render_chunk): 32-bit indices
+        const uint32_t groups = (uint32_t)(fd.tile_w + kCkpt - 1) / (uint32_t)kCkpt;
+        const uint32_t cs = (uint32_t)fd.tile_h;
+        const float *c = ckpt + (((uint32_t)f * groups + (uint32_t)xrel / (uint32_t)kCkpt) * 6u * cs + (uint32_t)yrel);
         float hx = c[0], hy = c[cs], hz = c[2 * cs], lx = c[3 * cs], ly = c[4 * cs], lz = c[5 * cs];
-        const int extra = xrel % kTile;
+        const int extra = xrel % kCkpt;
         for (int i = 0; i < extra; ++i) {                 // main.cpp:282-283
             hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];
             lx = lx + fd.xdiff_lo[0]; ly = ly + fd.xdiff_lo[1]; lz = lz + fd.xdiff_lo[2];

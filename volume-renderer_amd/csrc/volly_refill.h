@@ -69,7 +69,7 @@ render_frames_refill(DenseDev target, DenseDev low, const volly_frame_desc *__re
     const uint32_t my_tiles = min((uint32_t)(kRaysPerWave / 64), n_tiles - first_tile);
     const uint32_t total = my_tiles * 64u;
     const size_t frame_px = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h;
-    const int groups = tiles_x;
+    const int groups = (fd.tile_w + kCkpt - 1) / kCkpt;         // checkpoint groups per row
     const bool naive = (fd.flags & VOLLY_FRAME_NAIVE) != 0;
 
     // lane state
@@ -121,9 +121,9 @@ render_frames_refill(DenseDev target, DenseDev low, const volly_frame_desc *__re
                     if (xrel < fd.tile_w && yrel < fd.tile_h) {
                         pix = (uint32_t)yrel * (uint32_t)fd.tile_w + (uint32_t)xrel;
                         const size_t cs = (size_t)fd.tile_h;
-                        const float *c = ckpt + ((size_t)f * (size_t)groups + (size_t)(xrel / kTile)) * 6 * cs + (size_t)yrel;
+                        const float *c = ckpt + ((size_t)f * (size_t)groups + (size_t)(xrel / kCkpt)) * 6 * cs + (size_t)yrel;
                         float hx = c[0], hy = c[cs], hz = c[2 * cs], lx = c[3 * cs], ly = c[4 * cs], lz = c[5 * cs];
-                        const int extra = xrel % kTile;
+                        const int extra = xrel % kCkpt;
                         for (int i = 0; i < extra; ++i) { // main.cpp:282-283
                             hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];
                             lx = lx + fd.xdiff_lo[0]; ly = ly + fd.xdiff_lo[1]; lz = lz + fd.xdiff_lo[2];
