@@ -27,11 +27,12 @@ int main(int argc, char **argv)
         state.mouseY = argc > 6 ? std::atoi(argv[6]) : 0;
         if (argc > 9) state.camPos = volly::vec3((float)std::atof(argv[7]), (float)std::atof(argv[8]), (float)std::atof(argv[9]));
         const int W = state.renderTargetSizeX, H = state.renderTargetSizeY;
-        std::vector<uint32_t> pixels((size_t)W * H);
+        volly::gpu::Texture screenTex(W, H);               // the reference's screenTex (main.h:113), minus SDL
+        uint32_t *pixels = screenTex.data_stream;
         for (int f = 0; f < frames; ++f) {
             auto t0 = std::chrono::steady_clock::now();
             state.resolveUserInput();
-            state.raycastOntoScreen(pixels.data());
+            state.raycastOntoScreen(pixels);
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::printf("Frame : %d\n\tCur Frame Time: %.3f\n\tCasting %d*%d rays per frame, this is %.0f raycasts per second\n"
                         "\ton a %d*%d*%d dataset.\n", state.frame, ms, W, H, W * H * (1000.0 / ms),
@@ -41,7 +42,8 @@ int main(int argc, char **argv)
         FILE *fp = std::fopen(argv[4], "wb");
         if (!fp) { std::perror(argv[4]); return 1; }
         std::fprintf(fp, "P6\n%d %d\n255\n", W, H);
-        for (uint32_t p : pixels) {
+        for (size_t i = 0; i < (size_t)W * H; ++i) {
+            const uint32_t p = pixels[i];
             unsigned char rgb[3] = {(unsigned char)(p >> 8), (unsigned char)(p >> 16), (unsigned char)(p >> 24)};
             std::fwrite(rgb, 1, 3, fp);
         }

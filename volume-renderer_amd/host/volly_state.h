@@ -62,6 +62,25 @@ private:
     volly_gpu_scene *h_ = nullptr;
 };
 
+// The pixel memory Texture_SDL::lock() used to hand out (main.h:27-49): page-locked, so that
+// volume_gpu_render copies frames back while it still traverses (volly_gpu_host_alloc).
+class Texture {
+public:
+    Texture(int w, int h) : w_(w), h_(h), data_stream((uint32_t *)volly_gpu_host_alloc((size_t)w * (size_t)h * 4))
+    {
+        if (!data_stream) throw std::runtime_error(std::string("volly_gpu_host_alloc: ") + volly_gpu_last_error());
+    }
+    Texture(const Texture &) = delete;
+    Texture &operator=(const Texture &) = delete;
+    ~Texture() { volly_gpu_host_free(data_stream); }
+    int width() const { return w_; }
+    int height() const { return h_; }
+private:
+    int w_, h_;
+public:
+    uint32_t *data_stream;          // u8vec4(255, r, g, b) at [x + y*W], main.cpp:269-271
+};
+
 } // namespace gpu
 
 // main.h:58-72 without SDL: scancodes are plain ints chosen by the caller
