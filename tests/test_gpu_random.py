@@ -1,0 +1,112 @@
+"""Seeded differential test: random scenes x random cameras x random frame shapes, GPU (through
+the C-ABI) against the oracle, all five planes bit for bit.  The cases are drawn to reach every
+traversal path: grids made of whole 16^3 regions (the regular loop, with and without the region
+level) and grids that are not (the checked loop), octree and dense targets, beam / naive /
+raytrace frames, cameras outside, inside and on cell boundaries, sub-rectangles, axis-parallel
+views (zero direction components) and several frames per call."""
+import numpy as np
+import pytest
+
+from conftest import MISS, assert_planes_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_grid(rng, shape, density, blobs):
+    sz, sy, sx = shape
+    v = np.zeros((sz, sy, sx, 8), np.uint8)
+    fill = rng.random((sz, sy, sx)) < density
+    z, y, x = np.meshgrid(np.arange(sz), np.arange(sy), np.arange(sx), indexing="ij")
+    for _ in range(blobs):
+        c = rng.random(3) * (sz, sy, sx)
+        r = rng.uniform(2, max(3, min(shape) / 3))
+        fill |= (z - c[0]) ** 2 + (y - c[1]) ** 2 + (x - c[2]) ** 2 < r * r
+    n = int(fill.sum())
+    v[fill, 0:3] = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    v[fill, 3] = rng.integers(1, 256, n, dtype=np.uint8)
+    v[fill, 4:7] = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    return v
+
+
+def _low_of(v, f):
+    sz, sy, sx = v.shape[:3]
+    lz, ly, lx = -(-sz // f), -(-sy // f), -(-sx // f)
+    pad = np.zeros((lz * f, ly * f, lx * f), bool)
+    pad[:sz, :sy, :sx] = v[..., 3] > 0
+    any_ = pad.reshape(lz, f, ly, f, lx, f).any(axis=(1, 3, 5))
+    low = np.zeros((lz, ly, lx, 8), np.uint8)
+    low[any_, 0:4] = 255
+    return low
+
+
+CASES = list(range(36))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_random_scene_camera_frame(vra, ora, case):
+    rng = np.random.default_rng(1000 + case)
+    regular = case % 3 != 2
+    if regular:
+        shape = tuple(int(16 * rng.integers(1, 5)) for _ in range(3))
+    else:
+        shape = tuple(int(rng.integers(5, 50)) for _ in range(3))
+    cubic_pow2 = case % 4 == 0
+    if cubic_pow2:
+        shape = (int(2 ** rng.integers(4, 7)),) * 3
+    density = [0.0, 0.002, 0.02, 0.3][case % 4]
+    vox = _random_grid(rng, shape, density, blobs=int(rng.integers(0, 4)))
+    low = _low_of(vox, int(rng.choice([2, 4, 8])))
+    use_svo = cubic_pow2 and case % 8 == 0
+    scene = vra.HostScene.from_dense(vox, low, svo=use_svo)
+    gpu = vra.GpuScene.upload_svo(scene.svo, scene.low) if use_svo else vra.GpuScene.upload_dense(scene.target, scene.low)
+    hi = (shape[2], shape[1], shape[0])
+    lo = (low.shape[2], low.shape[1], low.shape[0])
+    w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+    frames = []
+    for k in range(int(rng.integers(1, 4))):
+        kind = (case + k) % 5
+        if kind == 0:                                   # inside the volume
+            pos = rng.random(3)
+        elif kind == 1:                                 # on a cell boundary of the target grid
+            pos = np.round(rng.random(3) * np.array(hi)) / np.array(hi)
+        else:                                           # outside, anywhere around
+            pos = 0.5 + (rng.random(3) - 0.5) * rng.uniform(1.2, 4.0)
+        if kind == 3:                                   # axis-parallel view: zero direction components
+            d = np.zeros(3)
+            d[int(rng.integers(0, 3))] = rng.choice([-1.0, 1.0])
+            center = pos + d
+        else:
+            center = rng.random(3)
+        if np.allclose(center, pos):
+            center = pos + np.array([0.3, 0.2, 0.1])
+        up = (0, 0, -1) if abs((center - pos)[2]) < 0.9 * np.linalg.norm(center - pos) else (0, 1, 0)
+        view = vra.look_at(pos.astype(np.float32), center.astype(np.float32), up)
+        mode = int(rng.integers(0, 3)) if not use_svo else int(rng.integers(0, 2))
+        f = vra.frame_from_camera(view, pos.astype(np.float32), hi, lo, w, h, naive=mode == 1, raytrace=mode == 2)
+        frames.append(f)
+    if rng.random() < 0.4 and w > 3 and h > 3:          # a sub-rectangle of the frame(s)
+        x0, y0 = int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))
+        tw, th = int(rng.integers(1, w - x0 + 1)), int(rng.integers(1, h - y0 + 1))
+        for f in frames:
+            f.x0, f.y0, f.tile_w, f.tile_h = x0, y0, tw, th
+    got = gpu.render(frames)
+    for i, f in enumerate(frames):
+        want = ora.render_frame(f, low=scene.low, svo=scene.svo) if use_svo else ora.render_frame(f, low=scene.low, target=scene.target)
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"case {case} frame {i} shape {shape} flags {f.flags}")
+    gpu.close()
+    scene.close()
+
+
+def test_the_random_cases_reach_hits_and_misses(vra, ora):
+    """Guard against a vacuous suite: over a few of the cases above there must be hits, misses
+    and rays that take steps in both grids."""
+    rng = np.random.default_rng(7)
+    vox = _random_grid(rng, (32, 48, 64), 0.01, blobs=3)
+    low = _low_of(vox, 4)
+    scene = vra.HostScene.from_dense(vox, low, svo=False)
+    pos, view = vra.orbit_camera(3, 16, 1.1)
+    f = vra.frame_from_camera(view, pos, (64, 48, 32), (16, 12, 8), 80, 60)
+    want = ora.render_frame(f, low=scene.low, target=scene.target)
+    assert (want["hit_index"] != MISS).sum() > 200 and (want["hit_index"] == MISS).sum() > 200
+    assert (want["steps_lo"] > 0).sum() > 1000 and (want["steps_hi"] > 0).sum() > 200
+    scene.close()
