@@ -29,7 +29,7 @@ host: $(LIBDIR)/libvolly_host.so
 oracle: oracle/libvolly_oracle.so
 
 GPU_SRC := $(PKG)/csrc/volly_gpu.hip $(PKG)/csrc/volly_voxelize.hip
-GPU_HDR := $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_refill.h $(PKG)/csrc/volly_internal.h include/volly_gpu.h
+GPU_HDR := $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_refill.h $(PKG)/csrc/volly_requeue.h $(PKG)/csrc/volly_internal.h include/volly_gpu.h
 
 $(LIBDIR)/libvolly_gpu.so: $(GPU_SRC) $(GPU_HDR)
 	@mkdir -p $(LIBDIR)

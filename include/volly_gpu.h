@@ -197,7 +197,7 @@ int volly_gpu_read_low_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t c
 int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leaves);
 
 /* Scene facts: 0 sx, 1 sy, 2 sz, 3 is_svo, 4 has_low, 5 low sx, 6 device,
- * 7 device bytes held (MiB), 8 frame kernel (0 tile per wavefront, 1 ray refill),
+ * 7 device bytes held (MiB), 8 frame kernel (0 tile per wavefront, 1 ray refill, 2 budgeted rounds with parked rays),
  * 9 target grid uses the 16^3 region level, 10 octree nodes, 11 octree leaves,
  * 12 octree depth, 13 a dense target grid is held. */
 int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);

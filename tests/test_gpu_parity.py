@@ -373,6 +373,42 @@ def test_ray_refill_kernel(vra, ora, teapot64, sphere64, monkeypatch):
     gpu.close()
 
 
+@pytest.mark.parametrize("budget", ["1", "7", "40"])
+def test_budgeted_rounds_with_parked_rays(vra, ora, teapot64, sphere64, monkeypatch, budget):
+    """The frame kernels of volly_requeue.h (VOLLY_REQUEUE=1): rays are traced up to an iteration
+    budget, parked, and continued by follow-up launches.  Tiny budgets force many rounds and
+    rays parked at every stage of their life; the planes must equal the oracle's bit for bit,
+    for beam and naive frames, odd sizes, sub-rectangles, a batch and degenerate rays."""
+    monkeypatch.setenv("VOLLY_REQUEUE", "1")
+    monkeypatch.setenv("VOLLY_REQUEUE_BUDGET", budget)
+    for scene in (teapot64, sphere64):
+        hi, lo = _sizes(scene)
+        gpu = vra.GpuScene.upload_dense(scene.target, scene.low)
+        assert gpu.info(8) == 2
+        frames = list(vra.orbit_frames(range(0, 16, 5), 16, hi, lo, 150, 77, radius=0.9))
+        frames += list(vra.orbit_frames((3,), 16, hi, lo, 150, 77, radius=0.6, naive=True))
+        got = gpu.render(frames)
+        for i, f in enumerate(frames):
+            assert_planes_equal({k: v[i] for k, v in got.items()}, _oracle(ora, f, scene, "dense"), f"requeue frame {i}")
+        sub = frames[1].copy()
+        sub.x0, sub.y0, sub.tile_w, sub.tile_h = 33, 9, 70, 41
+        assert_planes_equal({k: v[0] for k, v in gpu.render(sub).items()}, _oracle(ora, sub, scene, "dense"), "requeue sub")
+        for row0, org in (((1, 0, 0), (-5, 32.5, 32.5)), ((0, 0, 0), (10, 10, 10)), ((1, 0, 0), (-5, -2.0, 32.5)),
+                          ((1, 1, 1), (-1, -1, -1))):
+            f = _manual_frame(vra, 16, 8, row0, (0, 0.25, 0), (0, 0, 0.25), org)
+            assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, _oracle(ora, f, scene, "dense"),
+                                f"requeue degenerate {row0} {org}")
+        # raytrace frames take the tile kernel of the raytrace instantiation, as before
+        pos, view = vra.orbit_camera(6, 16, 0.7)
+        f = vra.frame_from_camera(view, pos, hi, lo, 64, 40, raytrace=True)
+        assert_planes_equal({p: v[0] for p, v in gpu.render(f).items()}, ora.render_frame(f, target=scene.target), "requeue raytrace")
+        gpu.close()
+    monkeypatch.setenv("VOLLY_REQUEUE", "0")
+    gpu = vra.GpuScene.upload_dense(teapot64.target, teapot64.low)
+    assert gpu.info(8) == 0
+    gpu.close()
+
+
 def test_raytrace_frames(vra, ora, teapot64, sphere64):
     """VOLLY_FRAME_RAYTRACE: raytrace_naiive (main.cpp:170-194) with the solid-mode traversal
     raycast_naiive_vec4<true>; colour and primary-ray planes bit-exact against the oracle."""

@@ -2,6 +2,7 @@
 // Built for gfx950 only, with -ffp-contract=off (see volly_kernels.h).
 #include "volly_internal.h"
 #include "volly_refill.h"
+#include "volly_requeue.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -111,6 +112,7 @@ void destroy(volly_gpu_scene *s)
     if (s->d_frames) (void)hipFree(s->d_frames);
     if (s->d_ckpt) (void)hipFree(s->d_ckpt);
     if (s->d_planes) (void)hipFree(s->d_planes);
+    if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->s_render) (void)hipStreamDestroy(s->s_render);
     if (s->s_copy) (void)hipStreamDestroy(s->s_copy);
     delete s;
@@ -143,6 +145,15 @@ void choose_frame_kernel(volly_gpu_scene *s)
     bool want = false;
     if (const char *e = std::getenv("VOLLY_REFILL")) want = ok && std::atoi(e) != 0;
     s->refill = want;
+    // Budgeted rounds with a queue of parked rays (volly_requeue.h), meant for scenes whose ray
+    // lengths scatter.  Measured on the 1024^3 noise volume it gains 5 % at best (3.62 against
+    // 3.81 ms, budget 160): there a step costs twice the arithmetic because nearly every step
+    // enters a new brick, the tile kernel's lanes are busy half of the time, not a fifth, and the
+    // later rounds lose the coherence of neighbouring rays.  Kept as an opt-in: VOLLY_REQUEUE=1.
+    const bool eligible = !s->is_svo && host_grid_is_regular(s->target);
+    bool rq = false;
+    if (const char *e = std::getenv("VOLLY_REQUEUE")) rq = eligible && std::atoi(e) != 0;
+    s->requeue = rq && !s->refill;
 }
 
 int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res)
@@ -231,7 +242,38 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     dim3 grid((unsigned)((tw + vk::kBlockW - 1) / vk::kBlockW), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
     bool any_raytrace = false;
     for (int i = 0; i < n; ++i) any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
-    if (s->refill && !any_raytrace) {
+    if (s->requeue && !any_raytrace) {
+        const size_t n_px = (size_t)n * tw * th;
+        if (n_px >= (1ull << 32)) return fail(VOLLY_E_ARG, "render: more than 2^32 pixels per launch");
+        if (n_px > s->queue_rays) {
+            if (s->d_queue) { HIP_TRY(hipFree(s->d_queue)); s->d_queue = nullptr; s->queue_rays = 0; }
+            HIP_TRY(hipMalloc(&s->d_queue, 64 + 2 * n_px * sizeof(vk::RayState)));
+            s->queue_rays = n_px;
+        }
+        uint32_t *counts = (uint32_t *)s->d_queue;                          // [0], [1]: the two queues' fill
+        vk::RayState *items = (vk::RayState *)((char *)s->d_queue + 64);
+        vk::QueueDev q[2] = {{items, counts, (uint32_t)n_px}, {items + s->queue_rays, counts + 1, (uint32_t)n_px}};
+        uint32_t budget = (uint32_t)std::min(std::max((s->target.sx + s->target.sy + s->target.sz) / 12, 32), 1024);
+        if (const char *e = std::getenv("VOLLY_REQUEUE_BUDGET")) budget = (uint32_t)std::max(std::atoi(e), 1);
+        HIP_TRY(hipMemsetAsync(counts, 0, 8, stream));
+        dim3 tiles((unsigned)((tw + vk::kTile - 1) / vk::kTile), (unsigned)((th + vk::kTile - 1) / vk::kTile), (unsigned)n);
+        hipLaunchKernelGGL(vk::render_frames_budget, tiles, dim3(64), 0, stream, s->target, s->low, s->d_frames, s->d_ckpt, o, q[0], budget);
+        HIP_TRY(hipGetLastError());
+        // every round continues the rays the previous one parked; the span doubles, and the last
+        // round runs to the iteration cap, where every ray ends
+        const unsigned cont_blocks = (unsigned)std::min<size_t>((n_px + 63) / 64, 8192);
+        int cur = 0;
+        for (uint32_t iter0 = budget, span = 2 * budget; iter0 < s->target.cap; iter0 += span, span *= 2) {
+            const bool last = (uint64_t)iter0 + span >= s->target.cap;
+            const uint32_t iter_end = last ? 0xFFFFFFFFu : iter0 + span;
+            HIP_TRY(hipMemsetAsync(q[cur ^ 1].count, 0, 4, stream));
+            hipLaunchKernelGGL(vk::continue_rays, dim3(cont_blocks), dim3(64), 0, stream, s->target, s->d_frames, (uint32_t)(tw * th), q[cur],
+                               q[cur ^ 1], o, iter0, iter_end);
+            HIP_TRY(hipGetLastError());
+            cur ^= 1;
+            if (last) break;
+        }
+    } else if (s->refill && !any_raytrace) {
         const unsigned tiles = (unsigned)((tw + vk::kTile - 1) / vk::kTile) * (unsigned)((th + vk::kTile - 1) / vk::kTile);
         const unsigned waves = (tiles + vk::kRaysPerWave / 64 - 1) / (vk::kRaysPerWave / 64);
         hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
@@ -548,7 +590,7 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 5: return s->has_low ? s->low.sx : 0;
     case 6: return s->device;
     case 7: return (int64_t)(s->bytes >> 20);
-    case 8: return s->refill;
+    case 8: return s->refill ? 1 : (s->requeue ? 2 : 0);
     case 9: return s->is_svo ? 0 : s->target.use_regions;
     case 10: return s->svo.nodes ? (int64_t)s->svo.n_nodes : 0;
     case 11: return s->svo.nodes ? (int64_t)s->n_leaves : 0;

@@ -47,7 +47,10 @@ struct DeviceGuard {
 struct volly_gpu_scene {
     int device = 0;
     bool is_svo = false, has_low = false;
-    bool refill = false;            // incoherent dense scene: use the ray-refill frame kernel
+    bool refill = false;            // use the ray-refill frame kernel (experiment, VOLLY_REFILL=1)
+    bool requeue = false;           // rays of very uneven length: budgeted rounds with a queue of parked rays (volly_requeue.h)
+    void *d_queue = nullptr;        // two queues of parked rays + their counters
+    size_t queue_rays = 0;
     vk::DenseDev target{}, low{};
     vk::SvoDev svo{};
     uint32_t n_leaves = 0;
