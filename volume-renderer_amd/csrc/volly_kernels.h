@@ -37,6 +37,7 @@
 //   VK_CKPT_STRIDE=4  a direction checkpoint every 4 pixels instead of 8 (at most 3 instead of 7
 //                     serial adds per lane and component, twice the checkpoint traffic: measured
 //                     1.4 % slower on config 2, 4 % on config 1)
+//   VK_INDEX24=0      32-bit multiplies for the brick / region index in the regular loop
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
 //   VK_WAVE_BLOCK=0   four wavefronts (a 32x8 pixel block) per workgroup with the output rows
 //                     staged through LDS into 128-byte stores, instead of one wavefront per
@@ -68,6 +69,9 @@
 #endif
 #ifndef VK_SHORT_DIV
 #define VK_SHORT_DIV 1
+#endif
+#ifndef VK_INDEX24
+#define VK_INDEX24 1
 #endif
 #ifndef VK_CKPT_STRIDE
 #define VK_CKPT_STRIDE 8
@@ -308,6 +312,17 @@ __device__ __forceinline__ uint32_t gather_bits(uint32_t masked)
     return (__umul24(masked, 0x00040404u) >> 18) & 63u;
 }
 
+// x + nx * (y + ny * z) for the bricks / regions of a regular grid (at most 256 per axis, so the
+// products stay below 2^24 and the 24-bit multiply-add does: 64-bit multiplies are quarter rate)
+__device__ __forceinline__ uint32_t cell_index24(int x, int y, int z, int nx, int ny)
+{
+#if VK_INDEX24
+    return __umul24((uint32_t)nx, __umul24((uint32_t)ny, (uint32_t)z) + (uint32_t)y) + (uint32_t)x;
+#else
+    return (uint32_t)x + (uint32_t)nx * ((uint32_t)y + (uint32_t)ny * (uint32_t)z);
+#endif
+}
+
 __device__ __forceinline__ bool test_word(uint32_t w_lo, uint32_t w_hi, uint32_t bit)
 {
     uint32_t w = (bit & 32u) ? w_hi : w_lo;
@@ -353,7 +368,7 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
         if (REGIONS && region != last_region) {
             bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
             if (inside) {
-                uint64_t bits = g.occ2[(uint32_t)(x >> 4) + (uint32_t)g.nrx * ((uint32_t)(y >> 4) + (uint32_t)g.nry * (uint32_t)(z >> 4))];
+                uint64_t bits = g.occ2[cell_index24(x >> 4, y >> 4, z >> 4, g.nrx, g.nry)];
                 r_lo = (uint32_t)bits;
                 r_hi = (uint32_t)(bits >> 32);
                 r_any = (r_lo | r_hi) != 0u;
@@ -371,7 +386,7 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
                 if (brick != last_brick) {
                     if (!REGIONS) inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
                     if (inside) {
-                        uint64_t bits = g.occ[(uint32_t)(x >> 2) + (uint32_t)g.nbx * ((uint32_t)(y >> 2) + (uint32_t)g.nby * (uint32_t)(z >> 2))];
+                        uint64_t bits = g.occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
                         w_lo = (uint32_t)bits;
                         w_hi = (uint32_t)(bits >> 32);
                         last_brick = brick;

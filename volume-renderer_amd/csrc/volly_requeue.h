@@ -63,7 +63,7 @@ __device__ __forceinline__ Hit trace_dense_span(const DenseDev &g, const Ray &r,
         if (REGIONS && region != last_region) {
             bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
             if (inside) {
-                uint64_t bits = g.occ2[(uint32_t)(x >> 4) + (uint32_t)g.nrx * ((uint32_t)(y >> 4) + (uint32_t)g.nry * (uint32_t)(z >> 4))];
+                uint64_t bits = g.occ2[cell_index24(x >> 4, y >> 4, z >> 4, g.nrx, g.nry)];
                 r_lo = (uint32_t)bits;
                 r_hi = (uint32_t)(bits >> 32);
                 r_any = (r_lo | r_hi) != 0u;
@@ -81,7 +81,7 @@ __device__ __forceinline__ Hit trace_dense_span(const DenseDev &g, const Ray &r,
                 if (brick != last_brick) {
                     if (!REGIONS) inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
                     if (inside) {
-                        uint64_t bits = g.occ[(uint32_t)(x >> 2) + (uint32_t)g.nbx * ((uint32_t)(y >> 2) + (uint32_t)g.nby * (uint32_t)(z >> 2))];
+                        uint64_t bits = g.occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
                         w_lo = (uint32_t)bits;
                         w_hi = (uint32_t)(bits >> 32);
                         last_brick = brick;
