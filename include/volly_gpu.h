@@ -101,13 +101,17 @@ typedef struct {
  *   hit_index x + sx*(y + sy*z) of the hit voxel (uint32 arithmetic), VOLLY_MISS_INDEX on a miss
  *   steps_lo  number of executions of the sample at main.cpp:137 in the low-grid pass (0 in NAIVE mode)
  *   steps_hi  same for the target-grid pass; for an SVO target: number of traversal iterations
- *   depth     dot(ptEnd - origin_hi, direction), evaluated (dx*vx + dy*vy) + dz*vz unfused; +inf on a miss */
+ *   depth     dot(ptEnd - origin_hi, direction), evaluated (dx*vx + dy*vy) + dz*vz unfused; +inf on a miss
+ *   pt_end    THREE floats per ray (x, y, z interleaved): RaycastReport::ptEnd of the target-grid pass
+ *             (main.cpp:81-86), the DDA position `cur` at the hit (main.cpp:143) or where the ray
+ *             stopped (main.cpp:129), in target-grid cell units */
 typedef struct {
     uint32_t *rgba8;
     uint32_t *hit_index;
     uint32_t *steps_lo;
     uint32_t *steps_hi;
     float    *depth;
+    float    *pt_end;
 } volly_outputs;
 
 /* Upload the target grid (State::getCurVol(), main.h:118) and the beam grid

@@ -392,6 +392,7 @@ static void render_row(const volly_frame_desc *f, int y, const float row_hi[3], 
                     o->rgba8[p] = hi.found ? vo_shade(hi.vox) : 255u;   /* u8vec4(255,0,0,0) */
                 }
             }
+            if (o->pt_end) memcpy(o->pt_end + 3 * p, hi.pt_end, 12);          /* RaycastReport::ptEnd of the target pass */
             if (o->hit_index) o->hit_index[p] = hi.hit_index;
             if (o->steps_lo)  o->steps_lo[p] = naive ? 0u : lo.steps;
             if (o->steps_hi)  o->steps_hi[p] = hi.steps;

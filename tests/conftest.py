@@ -53,6 +53,11 @@ def assert_planes_equal(got, want, what=""):
             bad = np.flatnonzero(g.reshape(-1) != w.reshape(-1))
             assert bad.size == 0, (f"{what} {plane}: {bad.size} of {g.size} differ, first at {bad[0]}: "
                                    f"got {g.reshape(-1)[bad[0]]} want {w.reshape(-1)[bad[0]]}")
+    if "pt_end" in got and "pt_end" in want:
+        g = np.asarray(got["pt_end"]).view(np.uint32).reshape(-1)
+        w = np.asarray(want["pt_end"]).view(np.uint32).reshape(-1)
+        bad = np.flatnonzero(g != w)
+        assert bad.size == 0, f"{what} pt_end: {bad.size} of {g.size} differ (bit patterns), first at {bad[0]}"
     if "depth" in got and "depth" in want:
         g = np.asarray(got["depth"]).view(np.uint32).reshape(-1)
         w = np.asarray(want["depth"]).view(np.uint32).reshape(-1)

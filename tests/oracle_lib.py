@@ -91,14 +91,14 @@ def raytrace(iteration, start, direction4, grid):
     return out, rep
 
 
-_DT = {"rgba8": np.uint32, "hit_index": np.uint32, "steps_lo": np.uint32, "steps_hi": np.uint32, "depth": np.float32}
+_DT = {"pt_end": np.float32, "rgba8": np.uint32, "hit_index": np.uint32, "steps_lo": np.uint32, "steps_hi": np.uint32, "depth": np.float32}
 PLANES = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")
 
 
 def render_frame(frame, low=None, target=None, svo=None, threads=8, planes=PLANES):
     """Oracle render of one frame's sub-rectangle: dict plane -> (tile_h, tile_w) array."""
-    res = {p: np.empty((frame.tile_h, frame.tile_w), _DT[p]) for p in planes}
-    outs = Outputs(*[res[p].ctypes.data if p in res else None for p in PLANES])
+    res = {p: np.empty((frame.tile_h, frame.tile_w, 3) if p == "pt_end" else (frame.tile_h, frame.tile_w), _DT[p]) for p in planes}
+    outs = Outputs(*[res[p].ctypes.data if p in res else None for p in PLANES + ("pt_end",)])
     rc = lib.vo_render_frame(C.byref(frame), _ref(low), _ref(target), _ref(svo), C.byref(outs), threads)
     if rc != 0:
         raise RuntimeError(f"vo_render_frame rc={rc}")

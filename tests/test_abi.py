@@ -24,7 +24,7 @@ def test_gpu_library_exports_every_declared_symbol(vra):
     for n in names:
         assert hasattr(vra.gpu.lib, n), f"libvolly_gpu.so does not export {n}"
     assert set(names) == set(vra.gpu.EXPORTS)
-    assert vra.gpu.lib.volly_gpu_abi_version() == 1
+    assert vra.gpu.lib.volly_gpu_abi_version() == 2
 
 
 def test_host_library_exports_every_declared_symbol(vra):
@@ -44,7 +44,7 @@ def test_struct_layouts_match_the_c_compiler(vra, tmp_path):
         "volly_frame_desc": (abi.FrameDesc, ["row0_hi", "xdiff_hi", "ydiff_hi", "row0_lo", "xdiff_lo", "ydiff_lo",
                                              "origin_lo", "origin_hi", "scale_lo_to_hi", "width", "height", "x0",
                                              "y0", "tile_w", "tile_h", "flags", "reserved"]),
-        "volly_outputs": (abi.Outputs, ["rgba8", "hit_index", "steps_lo", "steps_hi", "depth"]),
+        "volly_outputs": (abi.Outputs, ["rgba8", "hit_index", "steps_lo", "steps_hi", "depth", "pt_end"]),
         "volly_mesh_desc": (abi.MeshDesc, ["n_verts", "verts", "n_tris", "tris"]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "volly_gpu.h"', 'int main(void){']

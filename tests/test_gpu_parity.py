@@ -409,6 +409,46 @@ def test_budgeted_rounds_with_parked_rays(vra, ora, teapot64, sphere64, monkeypa
     gpu.close()
 
 
+def test_pt_end_plane_on_every_kernel(vra, ora, teapot64, monkeypatch):
+    """The optional sixth plane, RaycastReport::ptEnd (main.cpp:81-86): three floats per ray, hits
+    and misses, for dense and octree targets, beam / naive / raytrace frames, through the tile
+    kernel, the refill kernel and the budgeted rounds; alone and together with the other planes;
+    into pageable and into pinned memory."""
+    ALL = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth", "pt_end")
+    hi, lo = _sizes(teapot64)
+    frames = list(vra.orbit_frames((1, 9), 16, hi, lo, 101, 67, radius=0.9)) + list(vra.orbit_frames((4,), 16, hi, lo, 101, 67, naive=True))
+    for env in ({}, {"VOLLY_REFILL": "1"}, {"VOLLY_REQUEUE": "1", "VOLLY_REQUEUE_BUDGET": "9"}):
+        for k in ("VOLLY_REFILL", "VOLLY_REQUEUE", "VOLLY_REQUEUE_BUDGET"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for kind in ("dense", "svo"):
+            gpu = _upload(vra, teapot64, kind)
+            got = gpu.render(frames, planes=ALL)
+            only = gpu.render(frames, planes=("pt_end",))
+            for i, f in enumerate(frames):
+                want = (ora.render_frame(f, low=teapot64.low, target=teapot64.target, planes=ALL) if kind == "dense"
+                        else ora.render_frame(f, low=teapot64.low, svo=teapot64.svo, planes=ALL))
+                assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"pt_end {kind} {env} frame {i}")
+                assert np.array_equal(only["pt_end"][i].view(np.uint32), want["pt_end"].view(np.uint32))
+                assert np.isfinite(want["pt_end"]).all()
+            if kind == "dense":
+                pos, view = vra.orbit_camera(6, 16, 0.7)
+                f = vra.frame_from_camera(view, pos, hi, lo, 64, 40, raytrace=True)
+                assert_planes_equal({p: v[0] for p, v in gpu.render(f, planes=ALL).items()},
+                                    ora.render_frame(f, target=teapot64.target, planes=ALL), f"pt_end raytrace {env}")
+            gpu.close()
+    for k in ("VOLLY_REFILL", "VOLLY_REQUEUE", "VOLLY_REQUEUE_BUDGET"):
+        monkeypatch.delenv(k, raising=False)
+    gpu = _upload(vra, teapot64, "svo")
+    pin = vra.gpu.PinnedArray((len(frames), 67, 101, 3), np.float32)
+    pin_rgba = vra.gpu.PinnedArray((len(frames), 67, 101), np.uint32)
+    gpu.render_into(frames, {"pt_end": pin.array, "rgba8": pin_rgba.array})
+    ref = gpu.render(frames, planes=("pt_end", "rgba8"))
+    assert np.array_equal(pin.array.view(np.uint32), ref["pt_end"].view(np.uint32)) and np.array_equal(pin_rgba.array, ref["rgba8"])
+    pin.close(); pin_rgba.close(); gpu.close()
+
+
 def test_raytrace_frames(vra, ora, teapot64, sphere64):
     """VOLLY_FRAME_RAYTRACE: raytrace_naiive (main.cpp:170-194) with the solid-mode traversal
     raycast_naiive_vec4<true>; colour and primary-ray planes bit-exact against the oracle."""

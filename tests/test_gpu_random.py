@@ -11,6 +11,8 @@ from conftest import MISS, assert_planes_equal
 
 pytestmark = pytest.mark.gpu
 
+ALL = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth", "pt_end")     # pt_end: RaycastReport::ptEnd, 3 floats per ray
+
 
 def _random_grid(rng, shape, density, blobs):
     sz, sy, sx = shape
@@ -89,9 +91,10 @@ def test_random_scene_camera_frame(vra, ora, case):
         tw, th = int(rng.integers(1, w - x0 + 1)), int(rng.integers(1, h - y0 + 1))
         for f in frames:
             f.x0, f.y0, f.tile_w, f.tile_h = x0, y0, tw, th
-    got = gpu.render(frames)
+    got = gpu.render(frames, planes=ALL)
     for i, f in enumerate(frames):
-        want = ora.render_frame(f, low=scene.low, svo=scene.svo) if use_svo else ora.render_frame(f, low=scene.low, target=scene.target)
+        want = (ora.render_frame(f, low=scene.low, svo=scene.svo, planes=ALL) if use_svo
+                else ora.render_frame(f, low=scene.low, target=scene.target, planes=ALL))
         assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"case {case} frame {i} shape {shape} flags {f.flags}")
     gpu.close()
     scene.close()

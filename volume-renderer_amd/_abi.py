@@ -60,7 +60,8 @@ class FrameDesc(C.Structure):
 
 class Outputs(C.Structure):
     _fields_ = [("rgba8", C.c_void_p), ("hit_index", C.c_void_p), ("steps_lo", C.c_void_p),
-                ("steps_hi", C.c_void_p), ("depth", C.c_void_p)]
+                ("steps_hi", C.c_void_p), ("depth", C.c_void_p), ("pt_end", C.c_void_p)]
 
 
 PLANES = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")
+ALL_PLANES = PLANES + ("pt_end",)          # pt_end: three floats per ray, only on request

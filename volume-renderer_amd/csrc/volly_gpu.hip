@@ -232,6 +232,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     o.steps_lo = outs->steps_lo ? outs->steps_lo + px : nullptr;
     o.steps_hi = outs->steps_hi ? outs->steps_hi + px : nullptr;
     o.depth = outs->depth ? outs->depth + px : nullptr;
+    o.pt_end = outs->pt_end ? outs->pt_end + 3 * px : nullptr;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (s->profiling) {
@@ -299,7 +300,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
 
 extern "C" {
 
-int volly_gpu_abi_version(void) { return 1; }
+int volly_gpu_abi_version(void) { return 2; }
 
 const char *volly_gpu_last_error(void) { return g_err.c_str(); }
 
@@ -438,19 +439,21 @@ int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, in
     DeviceGuard g(scene->device);
     if (!g.ok) return fail(VOLLY_E_HIP, "hipSetDevice failed");
     const size_t px = (size_t)frames[0].tile_w * frames[0].tile_h * (size_t)n_frames;
-    void *host[5] = {outs->rgba8, outs->hit_index, outs->steps_lo, outs->steps_hi, outs->depth};
+    constexpr int kPlanes = 6;
+    void *host[kPlanes] = {outs->rgba8, outs->hit_index, outs->steps_lo, outs->steps_hi, outs->depth, outs->pt_end};
+    const size_t words[kPlanes] = {1, 1, 1, 1, 1, 3};      // 4-byte words per pixel
     size_t wanted = 0;
-    for (void *h : host) wanted += h ? 1 : 0;
+    for (int i = 0; i < kPlanes; ++i) wanted += host[i] ? words[i] : 0;
     if (wanted * px * 4 > scene->plane_bytes) {
         if (scene->d_planes) { HIP_TRY(hipFree(scene->d_planes)); scene->d_planes = nullptr; scene->plane_bytes = 0; }
         HIP_TRY(hipMalloc(&scene->d_planes, wanted * px * 4));
         scene->plane_bytes = wanted * px * 4;
     }
-    uint32_t *dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *dev[kPlanes] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t k = 0;
-    for (int i = 0; i < 5; ++i)
-        if (host[i]) dev[i] = (uint32_t *)scene->d_planes + (k++) * px;
-    volly_outputs d{dev[0], dev[1], dev[2], dev[3], (float *)dev[4]};
+    for (int i = 0; i < kPlanes; ++i)
+        if (host[i]) { dev[i] = (uint32_t *)scene->d_planes + k * px; k += words[i]; }
+    volly_outputs d{dev[0], dev[1], dev[2], dev[3], (float *)dev[4], (float *)dev[5]};
 
     // Output buffers in pinned host memory (volly_gpu_host_alloc, hipHostMalloc, hipHostRegister):
     // render a few frames at a time on one stream and copy each batch back on another, so the
@@ -481,9 +484,9 @@ int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, in
                 break;
             }
             evs.push_back(ev);
-            for (int i = 0; i < 5 && status == VOLLY_OK; ++i)
-                if (host[i] && hipMemcpyAsync((uint32_t *)host[i] + (size_t)first * fpx, dev[i] + (size_t)first * fpx, (size_t)n * fpx * 4,
-                                              hipMemcpyDeviceToHost, scene->s_copy) != hipSuccess)
+            for (int i = 0; i < kPlanes && status == VOLLY_OK; ++i)
+                if (host[i] && hipMemcpyAsync((uint32_t *)host[i] + (size_t)first * fpx * words[i], dev[i] + (size_t)first * fpx * words[i],
+                                              (size_t)n * fpx * 4 * words[i], hipMemcpyDeviceToHost, scene->s_copy) != hipSuccess)
                     status = fail(VOLLY_E_HIP, "render: copy to pinned host memory failed");
         }
         // render_chunk reuses the frame-descriptor and checkpoint scratch: a batch must not start
@@ -497,8 +500,8 @@ int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, in
 
     if ((rc = volume_gpu_render_device(scene, frames, n_frames, &d, nullptr))) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));
-    for (int i = 0; i < 5; ++i)
-        if (host[i]) HIP_TRY(hipMemcpy(host[i], dev[i], px * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < kPlanes; ++i)
+        if (host[i]) HIP_TRY(hipMemcpy(host[i], dev[i], px * 4 * words[i], hipMemcpyDeviceToHost));
     return VOLLY_OK;
 }
 

@@ -115,6 +115,7 @@ struct SvoDev {
 struct OutDev {
     uint32_t *rgba8, *hit_index, *steps_lo, *steps_hi;
     float *depth;
+    float *pt_end;                  // 3 floats per ray
 };
 
 #ifndef VOLLY_TYPES_ONLY            // (the other translation units of the library need only the types above)
@@ -670,6 +671,7 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
 
     uint32_t o_rgba = 255u, o_hit = VOLLY_MISS_INDEX, o_slo = 0, o_shi = 0;
     float o_depth = __uint_as_float(0x7F800000u);
+    float o_ex = 0.f, o_ey = 0.f, o_ez = 0.f;             // RaycastReport::ptEnd
 
     if (active) {
         // checkpoint scratch of one launch stays below 2^31 floats (render_chunk): 32-bit indices
@@ -695,6 +697,7 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
                 o_rgba = 255u | (tr << 8) | (tg << 16) | (tb << 24);
                 o_shi = prim.steps;
                 o_hit = prim.index;
+                o_ex = prim.cx; o_ey = prim.cy; o_ez = prim.cz;
                 if (prim.index != VOLLY_MISS_INDEX) {
                     float ddx = prim.cx - fd.origin_hi[0], ddy = prim.cy - fd.origin_hi[1], ddz = prim.cz - fd.origin_hi[2];
                     o_depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
@@ -718,6 +721,7 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
         Hit hi = SVO ? trace_svo(svo, top, ray_hi, sx, sy, sz) : trace_dense(target, ray_hi, sx, sy, sz);
         o_shi = hi.steps;
         o_hit = hi.index;
+        o_ex = hi.cx; o_ey = hi.cy; o_ez = hi.cz;
         if (hi.index != VOLLY_MISS_INDEX) {
             uint2 vox = SVO ? svo.leaves[hi.payload] : target.vox[hi.payload];
             o_rgba = shade(vox);
@@ -735,10 +739,15 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
         if (out.steps_lo) out.steps_lo[p] = o_slo;
         if (out.steps_hi) out.steps_hi[p] = o_shi;
         if (out.depth) out.depth[p] = o_depth;
+        if (out.pt_end) { out.pt_end[3 * p] = o_ex; out.pt_end[3 * p + 1] = o_ey; out.pt_end[3 * p + 2] = o_ez; }
     }
 #else
     // framebuffer writeback: through LDS so that every store instruction writes
     // whole 128-byte row segments (main.cpp:269-271 writes data_stream[x + y*W])
+    if (active && out.pt_end) {
+        const size_t q = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
+        out.pt_end[3 * q] = o_ex; out.pt_end[3 * q + 1] = o_ey; out.pt_end[3 * q + 2] = o_ez;
+    }
     stage[0][py_in_block][px_in_block] = o_rgba;
     stage[1][py_in_block][px_in_block] = o_hit;
     stage[2][py_in_block][px_in_block] = o_slo;

@@ -28,6 +28,7 @@ constexpr int kRefillAt = 16;       // refill when this many lanes are idle (or 
 struct LaneOut {
     uint32_t rgba, hit, slo, shi;
     float depth;
+    float ex, ey, ez;
 };
 
 __device__ __forceinline__ void store_pixel(const OutDev &out, size_t p, const LaneOut &o)
@@ -37,6 +38,7 @@ __device__ __forceinline__ void store_pixel(const OutDev &out, size_t p, const L
     if (out.steps_lo) out.steps_lo[p] = o.slo;
     if (out.steps_hi) out.steps_hi[p] = o.shi;
     if (out.depth) out.depth[p] = o.depth;
+    if (out.pt_end) { out.pt_end[3 * p] = o.ex; out.pt_end[3 * p + 1] = o.ey; out.pt_end[3 * p + 2] = o.ez; }
 }
 
 // main.cpp:262-272 for one finished ray
@@ -47,6 +49,7 @@ __device__ __forceinline__ void finish_pixel(const DenseDev &target, const volly
     LaneOut o;
     o.rgba = 255u; o.hit = hit_index; o.slo = slo; o.shi = shi;
     o.depth = __uint_as_float(0x7F800000u);
+    o.ex = cx; o.ey = cy; o.ez = cz;
     if (hit_index != VOLLY_MISS_INDEX) {
         o.rgba = shade(target.vox[hit_index]);
         float ddx = cx - fd.origin_hi[0], ddy = cy - fd.origin_hi[1], ddz = cz - fd.origin_hi[2];

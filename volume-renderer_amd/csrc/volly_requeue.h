@@ -139,6 +139,7 @@ __device__ __forceinline__ void write_pixel(const OutDev &out, size_t p, const D
     if (out.steps_lo) out.steps_lo[p] = steps_lo;
     if (out.steps_hi) out.steps_hi[p] = hi.steps;
     if (out.depth) out.depth[p] = o_depth;
+    if (out.pt_end) { out.pt_end[3 * p] = hi.cx; out.pt_end[3 * p + 1] = hi.cy; out.pt_end[3 * p + 2] = hi.cz; }
 }
 
 // First round: render_frames for a dense target (beam and naive frames), the target pass cut at

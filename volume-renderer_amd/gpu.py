@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from ._abi import (LIB_DIR, DenseDesc, SvoDesc, FrameDesc, MeshDesc, Outputs, PLANES, VOLLY_OK, VOX_DENSE, VOX_SVO)
+from ._abi import (LIB_DIR, DenseDesc, SvoDesc, FrameDesc, MeshDesc, Outputs, PLANES, ALL_PLANES, VOLLY_OK, VOX_DENSE, VOX_SVO)
 
 try:
     # torch ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one
@@ -101,7 +101,7 @@ class PinnedArray:
             pass
 
 
-_DT = {"rgba8": np.uint32, "hit_index": np.uint32, "steps_lo": np.uint32, "steps_hi": np.uint32, "depth": np.float32}
+_DT = {"pt_end": np.float32, "rgba8": np.uint32, "hit_index": np.uint32, "steps_lo": np.uint32, "steps_hi": np.uint32, "depth": np.float32}
 
 
 class GpuScene:
@@ -158,8 +158,8 @@ class GpuScene:
         """Synchronous render to host memory: dict plane -> (n_frames, tile_h, tile_w) array."""
         arr, n = _frames_array(frames)
         th, tw = arr[0].tile_h, arr[0].tile_w
-        res = {p: np.empty((n, th, tw), _DT[p]) for p in planes}
-        outs = Outputs(*[res[p].ctypes.data if p in res else None for p in PLANES])
+        res = {p: np.empty((n, th, tw, 3) if p == "pt_end" else (n, th, tw), _DT[p]) for p in planes}
+        outs = Outputs(*[res[p].ctypes.data if p in res else None for p in ALL_PLANES])
         _check(lib.volume_gpu_render(self._h, arr, n, C.byref(outs)), "volume_gpu_render")
         return res
 
@@ -168,14 +168,14 @@ class GpuScene:
         n_frames * tile_h * tile_w 4-byte elements), e.g. PinnedArray(...).array."""
         arr, n = _frames_array(frames)
         for p, a in arrays.items():
-            assert a.flags["C_CONTIGUOUS"] and a.size == n * arr[0].tile_h * arr[0].tile_w and a.itemsize == 4, p
-        outs = Outputs(*[arrays[p].ctypes.data if p in arrays else None for p in PLANES])
+            assert a.flags["C_CONTIGUOUS"] and a.size == n * arr[0].tile_h * arr[0].tile_w * (3 if p == "pt_end" else 1) and a.itemsize == 4, p
+        outs = Outputs(*[arrays[p].ctypes.data if p in arrays else None for p in ALL_PLANES])
         _check(lib.volume_gpu_render(self._h, arr, n, C.byref(outs)), "volume_gpu_render")
 
     def render_device(self, frames, ptrs, stream=None):
         """Asynchronous render into device memory.  ptrs: dict plane -> device pointer (int)."""
         arr, n = _frames_array(frames)
-        outs = Outputs(*[ptrs.get(p) for p in PLANES])
+        outs = Outputs(*[ptrs.get(p) for p in ALL_PLANES])
         _check(lib.volume_gpu_render_device(self._h, arr, n, C.byref(outs), stream), "volume_gpu_render_device")
 
     def set_profiling(self, on=True):
