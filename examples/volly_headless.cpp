@@ -20,7 +20,10 @@ int main(int argc, char **argv)
     }
     try {
         volly::State state;
-        state.initAllVolumes({argv[1]});
+        // VOLLY_DEVICE_VOXELIZE=1: build the four grids of the Vol_LOD_Set on the GPU as well
+        const char *dv = std::getenv("VOLLY_DEVICE_VOXELIZE");
+        if (dv && std::atoi(dv)) state.initAllVolumesOnDevice({argv[1]});
+        else state.initAllVolumes({argv[1]});
         state.curLoD = std::atoi(argv[2]);
         const int frames = std::atoi(argv[3]);
         state.mouseX = argc > 5 ? std::atoi(argv[5]) : 0;
@@ -36,7 +39,7 @@ int main(int argc, char **argv)
             double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::printf("Frame : %d\n\tCur Frame Time: %.3f\n\tCasting %d*%d rays per frame, this is %.0f raycasts per second\n"
                         "\ton a %d*%d*%d dataset.\n", state.frame, ms, W, H, W * H * (1000.0 / ms),
-                        state.getCurVol()->size.x, state.getCurVol()->size.y, state.getCurVol()->size.z);
+                        state.curVolSize().x, state.curVolSize().y, state.curVolSize().z);
             if (f + 1 < frames) state.mouseX += 7;
         }
         FILE *fp = std::fopen(argv[4], "wb");

@@ -184,6 +184,18 @@ typedef struct volly_mesh_desc {
 int volume_gpu_voxelize(int device, const volly_mesh_desc *mesh, int32_t res, int32_t flags,
                         volly_gpu_scene **out, int64_t *stats);
 
+/* The whole of Vol_LOD_Set's constructor (main.cpp:23-50, default resolutions 16/32/128/256,
+ * main.h:79) on the device: out[2] renders arr[2] = LoD 0 of the rasterisation at medR,
+ * out[1] arr[1] = its LoD 2 stored at lowR, out[0] arr[0] = its LoD 3 stored at sLowR,
+ * out[3] arr[3] = LoD 0 of a second rasterisation at highR (NULL when highR <= 0) -- each
+ * with arr[1] as its beam grid, the pair State::raycastOntoScreen takes for curLoD = i
+ * (main.h:118-119).  mesh_med is the polyhedron as the first rasterize call sees it (two
+ * normalizePoly passes), mesh_high as the second does (three): volly_host_mesh_load(path, 2 / 3).
+ * Dense grids, byte-identical to the host's Vol_LOD_Set (tests/test_gpu_voxelize.py). */
+int volume_gpu_voxelize_lod_set(int device, const volly_mesh_desc *mesh_med, const volly_mesh_desc *mesh_high,
+                                int32_t sLowR, int32_t lowR, int32_t medR, int32_t highR,
+                                volly_gpu_scene *out[4]);
+
 /* Kernel timing with HIP events on the stream the kernels are launched on.
  * While enabled every traversal-kernel launch is bracketed by an event pair;
  * volly_gpu_kernel_time waits for them, returns the summed milliseconds and the

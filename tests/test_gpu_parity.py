@@ -333,6 +333,12 @@ def test_reference_style_state_example(vra, ora, tmp_path):
         assert r.returncode == 0, r.stderr
         assert "raycasts per second" in r.stdout
         raw = ppm.read_bytes()
+        # the same State with its Vol_LOD_Set built on the GPU (State::initAllVolumesOnDevice)
+        ppm_dev = tmp_path / f"out{lod}_dev.ppm"
+        r = subprocess.run([exe, mesh, str(lod), "3", str(ppm_dev), "300", "500"] + [str(c) for c in cam], capture_output=True,
+                           text=True, timeout=120, env=dict(os.environ, VOLLY_DEVICE_VOXELIZE="1"))
+        assert r.returncode == 0, r.stderr
+        assert ppm_dev.read_bytes() == raw
         assert raw.startswith(b"P6\n400 300\n255\n")
         got = np.frombuffer(raw[len(b"P6\n400 300\n255\n"):], np.uint8).reshape(300, 400, 3)
         ls = vra.LodSet(mesh)

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ASSETS
+from conftest import ASSETS, assert_planes_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -138,3 +138,34 @@ def test_flat_mesh_gives_the_same_empty_scene(vra, tmp_path):
     p = str(tmp_path / "flat.off")
     _write_off(p, [(0, 0, 0.5), (1, 0, 0.5), (0, 1, 0.5), (1, 1, 0.5)], [(0, 1, 2), (1, 3, 2)])
     assert _compare_everything(vra, p, 32) == 0
+
+
+@pytest.mark.parametrize("mesh,res", [("galleon.ply", (16, 32, 128, 256)), ("icosahedron.ply", (16, 32, 128, 256)),
+                                      ("stratocaster.ply", (8, 16, 64, 96)), ("teapot.off", (16, 32, 128, 0))])
+def test_lod_set_on_the_device_equals_vol_lod_set(vra, ora, mesh, res):
+    """volume_gpu_voxelize_lod_set against the host's Vol_LOD_Set (main.cpp:23-50): all four
+    grids, the third normalizePoly pass that `high` sees, the beam grid every scene carries, and
+    a frame rendered at each level of detail."""
+    path = os.path.join(ASSETS, mesh)
+    sLowR, lowR, medR, highR = res
+    ls = vra.LodSet(path, sLowR, lowR, medR, highR)
+    m2, m3 = vra.HostMesh(path, 2), vra.HostMesh(path, 3)
+    scenes = vra.GpuScene.voxelize_lod_set(m2.desc, m3.desc if highR else None, sLowR, lowR, medR, highR)
+    assert (scenes[3] is None) == (highR == 0)
+    want_low = vra.host.dense_view(ls.grid(1)).reshape(-1, 8)
+    for lod, gpu in enumerate(scenes):
+        if gpu is None:
+            continue
+        tgt = ls.grid(lod)
+        want = vra.host.dense_view(tgt).reshape(-1, 8)
+        assert gpu.size == (tgt.sx, tgt.sy, tgt.sz)
+        got = gpu.read_voxels(0, tgt.sx * tgt.sy * tgt.sz)
+        assert np.array_equal(got, want), f"LoD {lod}: {int((got != want).any(axis=1).sum())} voxels differ"
+        assert np.array_equal(gpu.read_low_voxels(), want_low)
+        view = vra.look_at((0, 0, 0), vra.host.cam_dir_from_mouse(314, 500), (0, 0, -1))
+        f = vra.frame_from_camera(view, (0.9, -0.3, 0.6), (tgt.sx,) * 3, (lowR,) * 3, 100, 75)
+        assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, ora.render_frame(f, low=ls.grid(1), target=tgt), f"LoD {lod}")
+        gpu.close()
+    assert int((vra.host.dense_view(ls.grid(2))[..., 3] > 0).sum()) > 100
+    for o in (m2, m3, ls):
+        o.close()

@@ -761,15 +761,27 @@ int build_octree(volly_gpu_scene *s, const uint64_t *words, uint64_t n_words, in
     return finish_svo(s, nodes, leaves, (uint32_t)at, (uint32_t)n_leaves, depth, res);
 }
 
-int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags, int64_t *stats)
+// The search and its reduction to LoD 0: sorted (cell, last triangle) words
+struct Raster {
+    DevBuf rec;                     // TriRec per triangle (the scatter kernels read the normals)
+    DevBuf wa, wb;                  // wa: the current level's words, sorted, one per cell; wb: spare of the same size
+    uint64_t n = 0;                 // words in wa
+    int res = 0, level = 0;         // wa holds LoD `level` of a rasterisation at `res`
+    uint32_t tris_used = 0;
+    unsigned long long tests = 0, hits = 0;
+    int levels = 0;
+    uint64_t cells0 = 0;
+};
+
+int rasterize(const volly_mesh_desc *mesh, int res, Raster &out, Scratch &sc)
 {
-    using clock = std::chrono::steady_clock;
-    const auto t0 = clock::now();
-    Scratch sc;
     const int n_tris = (int)mesh->n_tris;
     const float resF = (float)(res - 1);                  // PLYfileReader.cpp:222
+    out.res = res;
+    out.level = 0;
 
-    DevBuf d_verts, d_tris, d_rec, d_bits, d_off;
+    DevBuf d_verts, d_tris, d_bits, d_off;
+    DevBuf &d_rec = out.rec;
     HIP_TRY(d_verts.alloc((size_t)mesh->n_verts * 16));
     HIP_TRY(d_tris.alloc((size_t)n_tris * 12));
     HIP_TRY(d_rec.alloc((size_t)n_tris * sizeof(vk::TriRec)));
@@ -819,9 +831,8 @@ int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags
     HIP_TRY(hipGetLastError());
     uint32_t hc[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(hc, counters.p, 16, hipMemcpyDeviceToHost));
-    const uint32_t tris_used = hc[3];
+    out.tris_used = hc[3];
     uint32_t count = hc[0];
-    int levels = 0;
     DevBuf *qin = &q0, *qout = &q1;
     while (count) {
         HIP_TRY(hipMemsetAsync(counters.p, 0, 4, 0));
@@ -834,12 +845,12 @@ int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags
             return fail(VOLLY_E_NOMEM, "volume_gpu_voxelize: search frontier larger than its queue (set VOLLY_VOX_QUEUE to a larger entry count)");
         std::swap(qin, qout);
         count = hc[0];
-        ++levels;
+        ++out.levels;
     }
     if (hc[2]) return fail(VOLLY_E_HIP, "volume_gpu_voxelize: internal error, a search left its triangle's box");
     unsigned long long h_tests[2] = {0, 0};
     HIP_TRY(hipMemcpy(h_tests, tests.p, 16, hipMemcpyDeviceToHost));
-    const unsigned long long n_tests = h_tests[0];
+    out.tests = h_tests[0];
     q0.reset(); q1.reset(); seen.reset();
     sc.sub((size_t)cap * 16 + n_bitwords * 4);
 
@@ -849,7 +860,8 @@ int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags
     HIP_TRY(hipMemset(n_hits.p, 0, 8));
     const unsigned emit_blocks = (unsigned)std::min<uint64_t>((n_bitwords + 255) / 256, 1u << 16);
     const unsigned long long hits = h_tests[1];          // counted by the search itself
-    DevBuf wa, wb;
+    out.hits = hits;
+    DevBuf &wa = out.wa, &wb = out.wb;
     HIP_TRY(wa.alloc((size_t)hits * 8)); HIP_TRY(wb.alloc((size_t)hits * 8));
     sc.add((size_t)hits * 16);
     if (hits) {
@@ -865,68 +877,111 @@ int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags
     sc.sub(n_bitwords * 4);
 
     // LoD 0: the last triangle of every cell
-    uint64_t n0 = hits;
-    int rc = sort_words(wa, wb, n0, 64, sc);
-    if (!rc) rc = keep_last_per_cell(wa, wb, &n0, sc);
+    out.n = hits;
+    int rc = sort_words(wa, wb, out.n, 64, sc);
+    if (!rc) rc = keep_last_per_cell(wa, wb, &out.n, sc);
     if (rc) return rc;
-    const uint64_t cells0 = n0;
+    out.cells0 = out.n;
+    return VOLLY_OK;
+}
 
-    if (flags & VOLLY_VOX_DENSE) {
-        if ((uint64_t)res * res * res > (1ull << 31))
-            return fail(VOLLY_E_ARG, "volume_gpu_voxelize: a dense target of more than 2^31 voxels (ask for VOLLY_VOX_SVO only)");
-        uint2 *vox = nullptr;
-        const size_t n = (size_t)res * res * res;
-        if ((rc = dev_alloc(s, (void **)&vox, n * 8))) return rc;
-        HIP_TRY(hipMemset(vox, 0, n * 8));
-        if (n0) {
-            hipLaunchKernelGGL(vk::vox_scatter, dim3(blocks_for(n0)), dim3(256), 0, 0, wa.as<uint64_t>(), n0, res, res, d_rec.as<vk::TriRec>(), vox);
-            HIP_TRY(hipGetLastError());
-        }
-        if ((rc = make_dense(s, res, res, res, nullptr, vox, &s->target))) return rc;
+// LoD k -> LoD k + 1 (PLYfileReader.cpp:284-286)
+int next_lod(Raster &r, Scratch &sc)
+{
+    int rc;
+    if (r.n) {
+        DevBuf flag;
+        HIP_TRY(flag.alloc(r.n));
+        hipLaunchKernelGGL(vk::vox_parent, dim3(blocks_for(r.n)), dim3(256), 0, 0, r.wa.as<uint64_t>(), r.n, r.wb.as<uint64_t>(), flag.as<uint8_t>());
+        HIP_TRY(hipGetLastError());
+        uint64_t kept = 0;
+        if ((rc = select_words(r.wb.as<uint64_t>(), flag.as<uint8_t>(), r.n, r.wa.as<uint64_t>(), &kept, sc))) return rc;
+        r.n = kept;
     }
-    if (flags & VOLLY_VOX_SVO) {
-        if ((rc = build_octree(s, wa.as<uint64_t>(), n0, res, d_rec.as<vk::TriRec>(), sc))) return rc;
-    }
+    if ((rc = sort_words(r.wa, r.wb, r.n, 64, sc))) return rc;
+    if ((rc = keep_last_per_cell(r.wa, r.wb, &r.n, sc))) return rc;
+    ++r.level;
+    return VOLLY_OK;
+}
 
-    // LoD 1, 2: the low beam grid is LoD 2 at res / 4 (main.cpp:33)
-    uint64_t nk = n0;
-    for (int lod = 1; lod <= 2; ++lod) {
-        if (nk) {
-            DevBuf flag;
-            HIP_TRY(flag.alloc(nk));
-            hipLaunchKernelGGL(vk::vox_parent, dim3(blocks_for(nk)), dim3(256), 0, 0, wa.as<uint64_t>(), nk, wb.as<uint64_t>(), flag.as<uint8_t>());
-            HIP_TRY(hipGetLastError());
-            uint64_t kept = 0;
-            if ((rc = select_words(wb.as<uint64_t>(), flag.as<uint8_t>(), nk, wa.as<uint64_t>(), &kept, sc))) return rc;
-            nk = kept;
-        }
-        if ((rc = sort_words(wa, wb, nk, 64, sc))) return rc;
-        if ((rc = keep_last_per_cell(wa, wb, &nk, sc))) return rc;
+// volumeFromVoxelMap(map, store, level) (volume.h:114-123) into a grid owned by scene s
+int dense_from_level(volly_gpu_scene *s, const Raster &r, int store, vk::DenseDev *out)
+{
+    if (store < 1 || (uint64_t)store * store * store > (1ull << 31))
+        return fail(VOLLY_E_ARG, "volume_gpu_voxelize: a dense grid of more than 2^31 voxels (ask for VOLLY_VOX_SVO only)");
+    const int level_res = r.res / (1 << r.level);
+    const size_t n = (size_t)store * store * store;
+    uint2 *vox = nullptr;
+    int rc = dev_alloc(s, (void **)&vox, n * 8);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(vox, 0, n * 8));
+    if (r.n) {
+        hipLaunchKernelGGL(vk::vox_scatter, dim3(blocks_for(r.n)), dim3(256), 0, 0, r.wa.as<uint64_t>(), r.n, level_res, store,
+                           r.rec.as<vk::TriRec>(), vox);
+        HIP_TRY(hipGetLastError());
     }
-    {
-        const int lr = res / 4;
-        const size_t n = (size_t)lr * lr * lr;
-        uint2 *vox = nullptr;
-        if ((rc = dev_alloc(s, (void **)&vox, n * 8))) return rc;
-        HIP_TRY(hipMemset(vox, 0, n * 8));
-        if (nk) {
-            hipLaunchKernelGGL(vk::vox_scatter, dim3(blocks_for(nk)), dim3(256), 0, 0, wa.as<uint64_t>(), nk, lr, lr, d_rec.as<vk::TriRec>(), vox);
-            HIP_TRY(hipGetLastError());
-        }
-        if ((rc = make_dense(s, lr, lr, lr, nullptr, vox, &s->low))) return rc;
-        s->has_low = true;
-    }
+    return make_dense(s, store, store, store, nullptr, vox, out);
+}
+
+int voxelize(volly_gpu_scene *s, const volly_mesh_desc *mesh, int res, int flags, int64_t *stats)
+{
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    Scratch sc;
+    Raster r;
+    int rc = rasterize(mesh, res, r, sc);
+    if (rc) return rc;
+    if (flags & VOLLY_VOX_DENSE)
+        if ((rc = dense_from_level(s, r, res, &s->target))) return rc;
+    if (flags & VOLLY_VOX_SVO)
+        if ((rc = build_octree(s, r.wa.as<uint64_t>(), r.n, res, r.rec.as<vk::TriRec>(), sc))) return rc;
+    // the low beam grid is LoD 2 at res / 4 (main.cpp:33)
+    if ((rc = next_lod(r, sc)) || (rc = next_lod(r, sc))) return rc;
+    if ((rc = dense_from_level(s, r, res / 4, &s->low))) return rc;
+    s->has_low = true;
     HIP_TRY(hipDeviceSynchronize());
     if (stats) {
-        stats[0] = tris_used;
-        stats[1] = (int64_t)n_tests;
-        stats[2] = (int64_t)hits;
-        stats[3] = levels;
-        stats[4] = (int64_t)cells0;
+        stats[0] = r.tris_used;
+        stats[1] = (int64_t)r.tests;
+        stats[2] = (int64_t)r.hits;
+        stats[3] = r.levels;
+        stats[4] = (int64_t)r.cells0;
         stats[5] = (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count();
         stats[6] = (int64_t)sc.peak;
         stats[7] = 0;
     }
+    return VOLLY_OK;
+}
+
+// Vol_LOD_Set's constructor (main.cpp:23-50): arr[2] = LoD 0 of the medR rasterisation, arr[1] =
+// its LoD 2 stored at lowR, arr[0] = its LoD 3 stored at sLowR, arr[3] = LoD 0 of a second
+// rasterisation at highR.  Scene i renders arr[i] with arr[1] as its beam grid, the pair
+// State::raycastOntoScreen uses for curLoD = i (main.h:118-119).
+int voxelize_lod_set(volly_gpu_scene *s[4], const volly_mesh_desc *mesh_med, const volly_mesh_desc *mesh_high, int sLowR, int lowR,
+                     int medR, int highR)
+{
+    Scratch sc;
+    int rc;
+    {
+        Raster r;
+        if ((rc = rasterize(mesh_med, medR, r, sc))) return rc;
+        if ((rc = dense_from_level(s[2], r, medR, &s[2]->target))) return rc;
+        if ((rc = next_lod(r, sc)) || (rc = next_lod(r, sc))) return rc;
+        if ((rc = dense_from_level(s[1], r, lowR, &s[1]->target))) return rc;
+        for (int i = 0; i < 4; ++i) {
+            if (!s[i]) continue;
+            if ((rc = dense_from_level(s[i], r, lowR, &s[i]->low))) return rc;
+            s[i]->has_low = true;
+        }
+        if ((rc = next_lod(r, sc))) return rc;
+        if ((rc = dense_from_level(s[0], r, sLowR, &s[0]->target))) return rc;
+    }
+    if (s[3]) {
+        Raster r;
+        if ((rc = rasterize(mesh_high, highR, r, sc))) return rc;
+        if ((rc = dense_from_level(s[3], r, highR, &s[3]->target))) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
     return VOLLY_OK;
 }
 
@@ -953,5 +1008,36 @@ extern "C" int volume_gpu_voxelize(int device, const volly_mesh_desc *mesh, int3
     if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
     choose_frame_kernel(s);
     *out = s;
+    return VOLLY_OK;
+}
+
+extern "C" int volume_gpu_voxelize_lod_set(int device, const volly_mesh_desc *mesh_med, const volly_mesh_desc *mesh_high, int32_t sLowR,
+                                           int32_t lowR, int32_t medR, int32_t highR, volly_gpu_scene *out[4])
+{
+    if (!out) return fail(VOLLY_E_ARG, "volume_gpu_voxelize_lod_set: out is null");
+    for (int i = 0; i < 4; ++i) out[i] = nullptr;
+    auto bad_mesh = [](const volly_mesh_desc *m) {
+        return !m || !m->verts || !m->tris || m->n_verts < 1 || m->n_tris < 1 || m->n_tris >= (1ll << vk::kVoxTriBits) || m->n_verts >= (1ll << 31);
+    };
+    if (bad_mesh(mesh_med) || (highR > 0 && bad_mesh(mesh_high))) return fail(VOLLY_E_ARG, "volume_gpu_voxelize_lod_set: empty or oversized mesh");
+    if (sLowR < 1 || lowR < 1 || medR < 8 || medR > 1024 || highR > 1024 || sLowR > 1024 || lowR > 1024)
+        return fail(VOLLY_E_ARG, "volume_gpu_voxelize_lod_set: resolutions must lie in [1, 1024], medR >= 8 (dense grids)");
+    volly_gpu_scene *s[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = VOLLY_OK;
+    for (int i = 0; i < 4 && !rc; ++i)
+        if (i < 3 || highR > 0) rc = new_scene(device, &s[i]);
+    if (!rc) {
+        DeviceGuard g(device);
+        if (!g.ok) rc = fail(VOLLY_E_HIP, "hipSetDevice failed");
+        else rc = voxelize_lod_set(s, mesh_med, mesh_high, sLowR, lowR, medR, highR);
+    }
+    if (rc) {
+        std::string keep = g_err;
+        for (auto *p : s) if (p) destroy(p);
+        g_err = keep;
+        return rc;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (s[i]) { choose_frame_kernel(s[i]); out[i] = s[i]; }
     return VOLLY_OK;
 }

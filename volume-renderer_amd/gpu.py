@@ -31,6 +31,8 @@ _sig = {
     "svo_gpu_upload": (C.c_int, [C.c_int, C.POINTER(SvoDesc), C.POINTER(DenseDesc), C.POINTER(_vp)]),
     "volume_gpu_generate_noise": (C.c_int, [C.c_int, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(_vp)]),
     "volume_gpu_voxelize": (C.c_int, [C.c_int, C.POINTER(MeshDesc), C.c_int32, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_int64)]),
+    "volume_gpu_voxelize_lod_set": (C.c_int, [C.c_int, C.POINTER(MeshDesc), C.POINTER(MeshDesc), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.POINTER(_vp)]),
     "volume_gpu_render": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs)]),
     "volume_gpu_render_device": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs), _vp]),
     "volly_gpu_host_alloc": (_vp, [C.c_size_t]),
@@ -141,6 +143,14 @@ class GpuScene:
         out = cls(h)
         out.vox_stats = dict(zip(("triangles", "tests", "pairs", "levels", "cells", "microseconds", "scratch_bytes"), list(stats)))
         return out
+
+    @classmethod
+    def voxelize_lod_set(cls, mesh_med, mesh_high, sLowR=16, lowR=32, medR=128, highR=256, device=0):
+        """volume_gpu_voxelize_lod_set: the four scenes of a Vol_LOD_Set (None for a missing high)."""
+        hs = (_vp * 4)()
+        _check(lib.volume_gpu_voxelize_lod_set(device, C.byref(mesh_med), C.byref(mesh_high) if mesh_high is not None else None,
+                                               sLowR, lowR, medR, highR, hs), "volume_gpu_voxelize_lod_set")
+        return [cls(_vp(h)) if h else None for h in hs]
 
     def info(self, what):
         return int(lib.volly_gpu_scene_info(self._h, what))

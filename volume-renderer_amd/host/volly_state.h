@@ -21,6 +21,7 @@
 
 #include "volly_scene.h"
 #include "../../include/volly_gpu.h"
+#include "../../include/volly_host.h"
 
 namespace volly {
 namespace gpu {
@@ -52,6 +53,12 @@ public:
         volly_dense_desc l{};
         if (low) l = low->desc();
         check(svo_gpu_upload(device, &t, low ? &l : nullptr, &s.h_), "svo_gpu_upload");
+        return s;
+    }
+    static Scene adopt(volly_gpu_scene *h)
+    {
+        Scene s;
+        s.h_ = h;
         return s;
     }
     static void check(int rc, const char *where)
@@ -124,6 +131,49 @@ struct State {
         }
     }
 
+    // The same with the four grids built on the GPU (volume_gpu_voxelize_lod_set) and never held
+    // on the host: getCurVol() and friends are not available for such a volume, curVolSize() is.
+    void initAllVolumesOnDevice(const std::vector<std::string> &meshPaths, int sLowR = 16, int lowR = 32, int medR = 128, int highR = 256)
+    {
+        for (const std::string &p : meshPaths) {
+            volly_host_mesh *m2 = volly_host_mesh_load(p.c_str(), 2), *m3 = highR > 0 ? volly_host_mesh_load(p.c_str(), 3) : nullptr;
+            if (!m2 || (highR > 0 && !m3)) {
+                std::string e = volly_host_last_error();
+                volly_host_mesh_free(m2); volly_host_mesh_free(m3);
+                throw std::runtime_error(e);
+            }
+            volly_mesh_desc d2{}, d3{};
+            volly_host_mesh_view(m2, &d2);
+            if (m3) volly_host_mesh_view(m3, &d3);
+            volly_gpu_scene *sc[4] = {nullptr, nullptr, nullptr, nullptr};
+            int rc = volume_gpu_voxelize_lod_set(device, &d2, m3 ? &d3 : nullptr, sLowR, lowR, medR, highR, sc);
+            volly_host_mesh_free(m2); volly_host_mesh_free(m3);
+            gpu::Scene::check(rc, "volume_gpu_voxelize_lod_set");
+            const int vol = (int)volumes.size();
+            volumes.push_back(nullptr);                     // no host grids for this volume
+            const int res[4] = {sLowR, lowR, medR, highR};
+            for (int lod = 0; lod < 4; ++lod) {
+                if (!sc[lod]) continue;
+                uploaded_.emplace(std::make_pair(vol, lod), gpu::Scene::adopt(sc[lod]));
+                deviceRes_[std::make_pair(vol, lod)] = res[lod];
+            }
+        }
+    }
+
+    // grid sizes of the current volume / LoD and of its beam grid, for either kind of volume
+    ivec3 curVolSize()
+    {
+        if (volumes[(size_t)curVolume]) return getCurVol()->size;
+        const int r = deviceRes_.at(std::make_pair(curVolume, curLoD));
+        return ivec3(r, r, r);
+    }
+    ivec3 curLowSize()
+    {
+        if (volumes[(size_t)curVolume]) return getCurVol_LowLOD()->size;
+        const int r = deviceRes_.at(std::make_pair(curVolume, 1));
+        return ivec3(r, r, r);
+    }
+
     // main.cpp:389-437 (mouse -> camDir -> view; keys -> camPos, LoD, model)
     void resolveUserInput()
     {
@@ -154,9 +204,8 @@ struct State {
     void raycastOntoScreen(uint32_t *data_stream)
     {
         gpu::Scene &scene = sceneFor(curVolume, curLoD);
-        VolumeStore<Voxel> *hi = getCurVol(), *lo = getCurVol_LowLOD();
         volly_frame_desc fd;
-        frame_from_camera(view, camPos, hi->size, lo->size, renderTargetSizeX, renderTargetSizeY, &fd);
+        frame_from_camera(view, camPos, curVolSize(), curLowSize(), renderTargetSizeX, renderTargetSizeY, &fd);
         volly_outputs out{};
         out.rgba8 = data_stream;
         gpu::Scene::check(volume_gpu_render(scene.get(), &fd, 1, &out), "volume_gpu_render");
@@ -165,10 +214,12 @@ struct State {
 
 private:
     std::map<std::pair<int, int>, gpu::Scene> uploaded_;
+    std::map<std::pair<int, int>, int> deviceRes_;          // resolution of the grids built on the device
     gpu::Scene &sceneFor(int vol, int lod)
     {
         auto key = std::make_pair(vol, lod);
         auto it = uploaded_.find(key);
+        if (it == uploaded_.end() && !volumes[(size_t)vol]) throw std::runtime_error("this level of detail was not built on the device");
         if (it == uploaded_.end())
             it = uploaded_.emplace(key, gpu::Scene::upload(*volumes[(size_t)vol]->arr[lod], volumes[(size_t)vol]->arr[1], device)).first;
         return it->second;
