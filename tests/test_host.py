@@ -275,3 +275,31 @@ def test_scene_cache_round_trip_and_rejection(vra, tmp_path):
             vra.HostScene.load(bad)
     with pytest.raises(RuntimeError):
         vra.HostScene.load(tmp_path / "nope.volly")
+
+
+def test_host_mesh_view_is_what_the_rasteriser_sees(vra):
+    """volly_host_mesh_load: vertices after n normalizePoly passes (PLYfileReader.cpp:141-171:
+    into the unit cube), triangle indices untouched; the descriptor is what
+    volume_gpu_voxelize takes.  The passes are not idempotent bit for bit, which is why the
+    count matters (Vol_LOD_Set's high grid sees three, main.cpp:27 + PLYfileReader.cpp:219)."""
+    import ctypes as C
+    path = os.path.join(ASSETS, "galleon.ply")
+    views = []
+    for n in (0, 1, 2, 3):
+        m = vra.HostMesh(path, n)
+        d = m.desc
+        assert d.n_verts == 2510 and d.n_tris == 4698
+        v = np.frombuffer((C.c_float * (4 * d.n_verts)).from_address(d.verts), np.float32).reshape(-1, 4).copy()
+        t = np.frombuffer((C.c_int32 * (3 * d.n_tris)).from_address(d.tris), np.int32).reshape(-1, 3).copy()
+        assert t.min() >= 0 and t.max() < d.n_verts
+        views.append((v, t))
+        m.close()
+    raw, once, twice, thrice = (v for v, _ in views)
+    assert raw[:, :3].max() > 1.5                                   # file coordinates
+    for v in (once, twice, thrice):
+        assert v[:, :3].min() >= 0.0 and v[:, :3].max() <= 1.0
+        assert np.isclose(v[:, :3].max(), 1.0) and np.isclose(v[:, :3].min(), 0.0, atol=1e-6)
+    assert np.allclose(once, twice, atol=1e-5) and np.allclose(twice, thrice, atol=1e-5)
+    assert all(np.array_equal(views[0][1], t) for _, t in views)
+    with pytest.raises(RuntimeError):
+        vra.HostMesh(os.path.join(ASSETS, "no_such_mesh.ply"), 2)
