@@ -41,7 +41,8 @@ def _low_of(v, f):
     return low
 
 
-CASES = list(range(36))
+import os
+CASES = list(range(int(os.environ.get("VOLLY_RANDOM_CASES", "36"))))   # a soak run sets a larger number
 
 
 @pytest.mark.parametrize("case", CASES)
