@@ -169,3 +169,31 @@ def test_lod_set_on_the_device_equals_vol_lod_set(vra, ora, mesh, res):
     assert int((vra.host.dense_view(ls.grid(2))[..., 3] > 0).sum()) > 100
     for o in (m2, m3, ls):
         o.close()
+
+
+SOUPS = list(range(int(os.environ.get("VOLLY_RANDOM_SOUPS", "8"))))     # a soak run sets a larger number
+
+
+@pytest.mark.parametrize("case", SOUPS)
+def test_random_triangle_soups_equal_the_host(vra, tmp_path, case):
+    """Random triangle soups -- a few huge triangles, many small ones, slivers, repeated vertices,
+    triangles in axis planes -- at random resolutions: target grid, low grid and octree equal the
+    host pipeline's."""
+    rng = np.random.default_rng(4000 + case)
+    nv = int(rng.integers(4, 200))
+    verts = rng.random((nv, 3))
+    if case % 3 == 0:
+        verts[rng.integers(0, nv, nv // 3), int(rng.integers(0, 3))] = rng.choice([0.0, 0.5, 1.0])    # many vertices in one axis plane
+    if case % 4 == 1:
+        verts = np.round(verts * 8) / 8                                                              # vertices on cell corners
+    nt = int(rng.integers(1, 300))
+    tris = rng.integers(0, nv, (nt, 3))
+    if case % 5 == 2:
+        local = rng.integers(0, nv, nt)                                                              # small triangles: nearby vertices
+        verts = np.vstack([verts, np.clip(verts[local] + rng.normal(0, 0.01, (nt, 3)), 0, 1),
+                           np.clip(verts[local] + rng.normal(0, 0.01, (nt, 3)), 0, 1)])
+        tris = np.stack([local, nv + np.arange(nt), nv + nt + np.arange(nt)], axis=1)
+    res = int(4 * rng.integers(2, 41))
+    p = str(tmp_path / "soup.off")
+    _write_off(p, verts, tris)
+    _compare_everything(vra, p, res)

@@ -813,46 +813,59 @@ int rasterize(const volly_mesh_desc *mesh, int res, Raster &out, Scratch &sc)
     DevBuf seen, pass;
     HIP_TRY(seen.alloc(n_bitwords * 4)); HIP_TRY(pass.alloc(n_bitwords * 4));
     sc.add(n_bitwords * 8);
-    HIP_TRY(hipMemset(seen.p, 0, n_bitwords * 4));
-    HIP_TRY(hipMemset(pass.p, 0, n_bitwords * 4));
 
-    // frontier queues: a level holds at most the cells first seen in the level before it
-    uint64_t cap64 = std::min<uint64_t>(std::max<uint64_t>(total_bits / 8, (uint64_t)3 * (uint64_t)n_tris + 1024), 1ull << 28);
-    if (const char *e = std::getenv("VOLLY_VOX_QUEUE")) cap64 = std::max<uint64_t>((uint64_t)std::atoll(e), (uint64_t)3 * (uint64_t)n_tris + 1024);
-    const uint32_t cap = (uint32_t)cap64;
+    // Frontier queues.  A level's frontier is the set of cells first seen in the level before it,
+    // so it can never hold more than total_bits entries; small searches get exactly that, large
+    // ones start with an eighth (their frontiers are surfaces, not volumes) and the search is run
+    // again with a larger queue should one ever fill up.
+    const uint64_t safe = total_bits + 3ull * (uint64_t)n_tris + 1024;
+    uint64_t cap64 = safe <= (1ull << 26) ? safe : std::min<uint64_t>(std::max<uint64_t>(total_bits / 8, 1ull << 26), 1ull << 28);
+    if (const char *e = std::getenv("VOLLY_VOX_QUEUE")) cap64 = std::max<uint64_t>((uint64_t)std::atoll(e), 3ull * (uint64_t)n_tris + 1024);
+    cap64 = std::max<uint64_t>(cap64, 3ull * (uint64_t)n_tris + 1024);       // vox_seed writes up to three entries per triangle
     DevBuf q0, q1, counters, tests;
-    HIP_TRY(q0.alloc((size_t)cap * 8)); HIP_TRY(q1.alloc((size_t)cap * 8));
     HIP_TRY(counters.alloc(16)); HIP_TRY(tests.alloc(16));
-    sc.add((size_t)cap * 16);
-    HIP_TRY(hipMemset(counters.p, 0, 16));
-    HIP_TRY(hipMemset(tests.p, 0, 16));
-    hipLaunchKernelGGL(vk::vox_seed, dim3(blocks_for((uint64_t)n_tris)), dim3(256), 0, 0, d_rec.as<vk::TriRec>(), d_off.as<uint64_t>(), n_tris,
-                       seen.as<uint32_t>(), q0.as<uint64_t>(), counters.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
     uint32_t hc[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(hc, counters.p, 16, hipMemcpyDeviceToHost));
-    out.tris_used = hc[3];
-    uint32_t count = hc[0];
-    DevBuf *qin = &q0, *qout = &q1;
-    while (count) {
-        HIP_TRY(hipMemsetAsync(counters.p, 0, 4, 0));
-        hipLaunchKernelGGL(vk::vox_level, dim3(blocks_for(count)), dim3(256), 0, 0, d_rec.as<vk::TriRec>(), d_off.as<uint64_t>(),
-                           qin->as<uint64_t>(), count, qout->as<uint64_t>(), cap, seen.as<uint32_t>(), pass.as<uint32_t>(), res,
-                           counters.as<uint32_t>(), tests.as<unsigned long long>());
+    for (;;) {
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 0x7FFFFFFFull);
+        HIP_TRY(q0.alloc((size_t)cap * 8)); HIP_TRY(q1.alloc((size_t)cap * 8));
+        sc.add((size_t)cap * 16);
+        HIP_TRY(hipMemset(seen.p, 0, n_bitwords * 4));
+        HIP_TRY(hipMemset(pass.p, 0, n_bitwords * 4));
+        HIP_TRY(hipMemset(counters.p, 0, 16));
+        HIP_TRY(hipMemset(tests.p, 0, 16));
+        hipLaunchKernelGGL(vk::vox_seed, dim3(blocks_for((uint64_t)n_tris)), dim3(256), 0, 0, d_rec.as<vk::TriRec>(), d_off.as<uint64_t>(), n_tris,
+                           seen.as<uint32_t>(), q0.as<uint64_t>(), counters.as<uint32_t>());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpy(hc, counters.p, 16, hipMemcpyDeviceToHost));
-        if (hc[1] || hc[0] > cap)
-            return fail(VOLLY_E_NOMEM, "volume_gpu_voxelize: search frontier larger than its queue (set VOLLY_VOX_QUEUE to a larger entry count)");
-        std::swap(qin, qout);
-        count = hc[0];
-        ++out.levels;
+        out.tris_used = hc[3];
+        out.levels = 0;
+        uint32_t count = hc[0];
+        bool overflow = false;
+        DevBuf *qin = &q0, *qout = &q1;
+        while (count && !overflow) {
+            HIP_TRY(hipMemsetAsync(counters.p, 0, 4, 0));
+            hipLaunchKernelGGL(vk::vox_level, dim3(blocks_for(count)), dim3(256), 0, 0, d_rec.as<vk::TriRec>(), d_off.as<uint64_t>(),
+                               qin->as<uint64_t>(), count, qout->as<uint64_t>(), cap, seen.as<uint32_t>(), pass.as<uint32_t>(), res,
+                               counters.as<uint32_t>(), tests.as<unsigned long long>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpy(hc, counters.p, 16, hipMemcpyDeviceToHost));
+            overflow = hc[1] || hc[0] > cap;
+            std::swap(qin, qout);
+            count = hc[0];
+            ++out.levels;
+        }
+        sc.sub((size_t)cap * 16);
+        if (!overflow) break;
+        if (cap64 >= safe || cap64 >= 0x7FFFFFFFull)
+            return fail(VOLLY_E_NOMEM, "volume_gpu_voxelize: search frontier larger than 2^31 entries");
+        cap64 = std::min<uint64_t>(cap64 * 4, safe);
     }
     if (hc[2]) return fail(VOLLY_E_HIP, "volume_gpu_voxelize: internal error, a search left its triangle's box");
     unsigned long long h_tests[2] = {0, 0};
     HIP_TRY(hipMemcpy(h_tests, tests.p, 16, hipMemcpyDeviceToHost));
     out.tests = h_tests[0];
     q0.reset(); q1.reset(); seen.reset();
-    sc.sub((size_t)cap * 16 + n_bitwords * 4);
+    sc.sub(n_bitwords * 4);
 
     // passing (cell, triangle) pairs with x > 1 -> words
     DevBuf n_hits;
