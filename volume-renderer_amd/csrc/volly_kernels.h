@@ -39,6 +39,8 @@
 //                     1.4 % slower on config 2, 4 % on config 1)
 //   VK_INDEX24=0      32-bit multiplies for the brick / region index in the regular loop
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
+//   VK_WAVE_BLOCK=N   N wavefronts (N tiles side by side) per workgroup, each storing its tile
+//                     straight from registers: no LDS, no barrier, 1/N of the workgroup dispatches
 //   VK_WAVE_BLOCK=0   four wavefronts (a 32x8 pixel block) per workgroup with the output rows
 //                     staged through LDS into 128-byte stores, instead of one wavefront per
 //                     workgroup storing its 8x8 tile straight from registers (no barrier at
@@ -83,10 +85,10 @@ namespace vk {
 
 constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
 constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pixels of a row (at most kCkpt - 1 adds per lane)
-constexpr int kBlockW = VK_WAVE_BLOCK ? 8 : 32;     // workgroup covers 8 x 8 (or 32 x 8) pixels
+constexpr int kBlockW = VK_WAVE_BLOCK ? 8 * VK_WAVE_BLOCK : 32;   // workgroup covers VK_WAVE_BLOCK tiles of 8 x 8 pixels side by side
 constexpr int kBlockH = 8;
 constexpr int kThreads = 256;
-constexpr int kFrameThreads = VK_WAVE_BLOCK ? 64 : 256;   // workgroup size of render_frames
+constexpr int kFrameThreads = VK_WAVE_BLOCK ? 64 * VK_WAVE_BLOCK : 256;   // workgroup size of render_frames
 constexpr int kTopNodes = VK_LDS_TOP ? 585 : 1;   // octree levels 0..3 (1 + 8 + 64 + 512 nodes) staged in LDS
 
 struct DenseDev {
