@@ -196,6 +196,12 @@ int volume_gpu_voxelize_lod_set(int device, const volly_mesh_desc *mesh_med, con
                                 int32_t sLowR, int32_t lowR, int32_t medR, int32_t highR,
                                 volly_gpu_scene *out[4]);
 
+/* t_c_intersection (triangleCube.c:213-319) as the device voxelizer runs it, on its own: n
+ * triangles of 9 floats each (three vertices relative to the centre of a unit cube), out[i] = 0
+ * (INSIDE: the triangle touches the cube) or 1 (OUTSIDE), the reference's return values
+ * (triangleCube.c:28-29).  Lets a test hold the device code against the reference's own function. */
+int volly_gpu_tricube(int device, const float *tri9, int64_t n, int32_t *out);
+
 /* Kernel timing with HIP events on the stream the kernels are launched on.
  * While enabled every traversal-kernel launch is bracketed by an event pair;
  * volly_gpu_kernel_time waits for them, returns the summed milliseconds and the

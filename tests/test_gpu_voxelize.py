@@ -197,3 +197,33 @@ def test_random_triangle_soups_equal_the_host(vra, tmp_path, case):
     p = str(tmp_path / "soup.off")
     _write_off(p, verts, tris)
     _compare_everything(vra, p, res)
+
+
+def test_device_cube_test_against_the_reference_function(vra):
+    """The device's t_c_intersection held directly against the reference's own triangleCube.c
+    (oracle/_ref, built from /root/reference where it lies) and against the host restatement, on
+    random, touching and degenerate triangles -- the same families as tests/test_host.py, more of
+    them."""
+    import ctypes as C
+    from conftest import ROOT
+    rng = np.random.default_rng(23)
+    tris = [rng.uniform(-s, s, size=(n, 9)) for s, n in ((0.4, 20000), (1.0, 80000), (3.0, 60000), (30.0, 10000))]
+    grid = np.array([-1.5, -1.0, -0.5, 0.0, 0.5, 1.0, 1.5])
+    tris.append(rng.choice(grid, size=(100000, 9)))
+    flat = rng.choice(grid, size=(10000, 9)); flat[:, 6:9] = flat[:, 0:3]
+    tris.append(flat)
+    near = rng.choice(grid, size=(40000, 9)) + rng.normal(0, 1e-4, (40000, 9))     # around the test's 1e-4 tolerance
+    tris.append(near)
+    t = np.concatenate(tris).astype(np.float32)
+    got = vra.gpu.tricube(t)
+    host = np.array([vra.host.lib.volly_host_tricube(row.ctypes.data_as(C.POINTER(C.c_float))) for row in t[:60000]], np.int32)
+    assert np.array_equal(got[:60000], host)
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libtricube_ref.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref/libtricube_ref.so not built (needs /root/reference at build time)")
+    ref = C.CDLL(ref_path).tricube_ref
+    ref.argtypes, ref.restype = [C.POINTER(C.c_float)], C.c_int
+    want = np.array([ref(row.ctypes.data_as(C.POINTER(C.c_float))) for row in t], np.int32)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, f"{bad.size} of {t.shape[0]} differ, first {t[bad[0]].tolist()}: device {got[bad[0]]}, reference {want[bad[0]]}"
+    assert 30000 < int((want == 0).sum()) < 250000

@@ -203,6 +203,15 @@ __device__ bool triangle_touches_unit_cube(P3 v1, P3 v2, P3 v3)
     return false;
 }
 
+// the cube test on its own: n triangles of 9 floats (already relative to the cube centre)
+__global__ void __launch_bounds__(256) vox_tricube_batch(const float *tri9, uint64_t n, int32_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *t = tri9 + 9 * i;
+    out[i] = triangle_touches_unit_cube({t[0], t[1], t[2]}, {t[3], t[4], t[5]}, {t[6], t[7], t[8]}) ? 0 : 1;
+}
+
 // ---- per-triangle set-up: PLYfileReader.cpp:225-248 ---------------------------------------
 // The bitmap box of a triangle holds every cell the search can look at: a cell passes only if
 // the triangle's bounding box reaches its cube (the first rejection of t_c_intersection), so
@@ -1052,5 +1061,24 @@ extern "C" int volume_gpu_voxelize_lod_set(int device, const volly_mesh_desc *me
     }
     for (int i = 0; i < 4; ++i)
         if (s[i]) { choose_frame_kernel(s[i]); out[i] = s[i]; }
+    return VOLLY_OK;
+}
+
+extern "C" int volly_gpu_tricube(int device, const float *tri9, int64_t n, int32_t *out)
+{
+    if (!tri9 || !out || n < 0) return fail(VOLLY_E_ARG, "volly_gpu_tricube: null argument");
+    if (n == 0) return VOLLY_OK;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(VOLLY_E_ARG, "no such device");
+    DeviceGuard g(device);
+    if (!g.ok) return fail(VOLLY_E_HIP, "hipSetDevice failed");
+    DevBuf d_in, d_out;
+    HIP_TRY(d_in.alloc((size_t)n * 36));
+    HIP_TRY(d_out.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(d_in.p, tri9, (size_t)n * 36, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(vk::vox_tricube_batch, dim3(blocks_for((uint64_t)n)), dim3(256), 0, 0, d_in.as<float>(), (uint64_t)n, d_out.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return VOLLY_OK;
 }

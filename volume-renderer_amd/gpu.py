@@ -33,6 +33,7 @@ _sig = {
     "volume_gpu_voxelize": (C.c_int, [C.c_int, C.POINTER(MeshDesc), C.c_int32, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_int64)]),
     "volume_gpu_voxelize_lod_set": (C.c_int, [C.c_int, C.POINTER(MeshDesc), C.POINTER(MeshDesc), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                               C.POINTER(_vp)]),
+    "volly_gpu_tricube": (C.c_int, [C.c_int, _vp, C.c_int64, _vp]),
     "volume_gpu_render": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs)]),
     "volume_gpu_render_device": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs), _vp]),
     "volly_gpu_host_alloc": (_vp, [C.c_size_t]),
@@ -77,6 +78,14 @@ def _frames_array(frames):
     for i, f in enumerate(frames):
         arr[i] = f
     return arr, len(frames)
+
+
+def tricube(tri9, device=0):
+    """volly_gpu_tricube: (n, 9) float32 triangles -> (n,) int32, 0 = touches the unit cube, 1 = outside."""
+    t = np.ascontiguousarray(tri9, dtype=np.float32).reshape(-1, 9)
+    out = np.empty(t.shape[0], np.int32)
+    _check(lib.volly_gpu_tricube(device, t.ctypes.data, t.shape[0], out.ctypes.data), "volly_gpu_tricube")
+    return out
 
 
 class PinnedArray:
