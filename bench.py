@@ -50,6 +50,8 @@ def parse():
                     help="one frame per step split into row bands over the ranks + gather to rank 0 (config 4)")
     ap.add_argument("--mode", choices=["beam", "naive"], default="beam",
                     help="beam = raycast_beamOpt (the reference's live path); naive = traversal from the camera")
+    ap.add_argument("--no-device-prepare", action="store_true",
+                    help="skip the (untimed) run of volume_gpu_voxelize on the same mesh and its comparison with the host scene")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend; gloo + --force-device rehearses the N>1 paths on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=None, help="use this GPU on every rank (rehearsal only)")
@@ -104,6 +106,35 @@ def main():
         data = f"bundled asset ({args.scene}) voxelized on the host, synthetic orbit cameras"
     size_hi, size_lo = (args.res,) * 3, (args.res // 4,) * 3
     setup_s = time.time() - t0
+
+    # the same scene prepared on the device (volume_gpu_voxelize), outside the timed region: how
+    # long it takes and whether octree / grids equal the host pipeline's (reported, rank 0)
+    prepare = None
+    if scene is not None and rank == 0 and not args.no_device_prepare:
+        try:
+            import numpy as np
+            mesh = vra.HostMesh(os.path.join(ROOT, "assets", args.scene), 2)
+            best = None
+            for _ in range(2):
+                t1 = time.time()
+                g2 = vra.GpuScene.voxelize(mesh.desc, args.res, dense=want_dense, svo=not want_dense, device=local_rank)
+                dt = time.time() - t1
+                best = dt if best is None else min(best, dt)
+                if _ == 0:
+                    g2.close()
+            same = bool(np.array_equal(g2.read_low_voxels(), vra.host.dense_view(scene.low).reshape(-1, 8)))
+            if want_dense:
+                same = same and bool(np.array_equal(g2.read_voxels(0, args.res ** 3), vra.host.dense_view(scene.target).reshape(-1, 8)))
+            else:
+                nh, lh = scene.svo_arrays()
+                ng, lg = g2.read_svo()
+                same = same and bool(np.array_equal(ng.view(np.uint64), nh.view(np.uint64)) and np.array_equal(lg, lh))
+            prepare = {"device_ms": round(best * 1e3, 1), "host_s": round(setup_s, 2), "equal_to_host": same,
+                       "cube_tests": g2.vox_stats["tests"], "search_levels": g2.vox_stats["levels"]}
+            g2.close()
+            mesh.close()
+        except Exception as e:      # reported, never fatal: this is not the measured path
+            prepare = {"error": str(e)[:200]}
 
     W, H, B = args.width, args.height, args.views
     naive = args.mode == "naive"
@@ -205,6 +236,8 @@ def main():
     }
     if assembled_ok is not None:
         out["config"]["assembled_frame_equals_single_gpu_frame"] = assembled_ok
+    if prepare is not None:
+        out["config"]["scene_prepared_on_device"] = prepare
     if launches:
         avg_ms = kern_ms / launches
         alg_per_launch = alg_bytes / launches
