@@ -26,13 +26,21 @@ planes = {q: torch.empty((nv, H, W), dtype=torch.float32 if q == "depth" else to
           for q in ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")}
 ptrs = {q: t.data_ptr() for q, t in planes.items()}
 gpu.set_profiling(True)
-for away in (False, True):
-    fr = frames(away)
+def measure(fr, p):
     ts = []
     for _ in range(8):
-        gpu.render_device(fr, ptrs)
+        gpu.render_device(fr, p)
         torch.cuda.synchronize()
         ms, n = gpu.kernel_time()
         ts.append(ms / n)
+    return statistics.median(ts)
+for away in (False, True):
+    fr = frames(away)
+    t = measure(fr, ptrs)
     steps = planes["steps_lo"].sum(dtype=torch.int64).item() / (nv * W * H)
-    print(f"{'looking away' if away else 'looking at the volume'}: kernel {statistics.median(ts):.4f} ms, mean low-grid steps {steps:.2f}")
+    print(f"{'looking away' if away else 'looking at the volume'}: kernel {t:.4f} ms, mean low-grid steps {steps:.2f}")
+fr = frames(True)
+print(f"looking away, rgba8 plane only: kernel {measure(fr, {'rgba8': ptrs['rgba8']}):.4f} ms")
+for f in fr:
+    f.flags = 1
+print(f"looking away, naive frames (no low-grid pass set-up): kernel {measure(fr, ptrs):.4f} ms")
