@@ -251,8 +251,8 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": ("vk::render_frames_refill" if gpu.info(8) else
-                                      "vk::render_frames<%s>" % ("true" if args.target == "svo" else "false")),
+                           "kernel": {1: "vk::render_frames_refill", 2: "vk::render_frames_budget + vk::continue_rays"}.get(
+                               gpu.info(8), "vk::render_frames<%s>" % ("true" if args.target == "svo" else "false")),
                            "kernel_avg_ms": round(avg_ms, 4), "launches": launches,
                            "algorithmic_bytes_per_launch": int(alg_per_launch)}
 
