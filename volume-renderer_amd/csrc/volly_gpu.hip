@@ -206,6 +206,14 @@ int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, in
     return VOLLY_OK;
 }
 
+// VOLLY_PROBE_LDS=<bytes>: dynamic LDS per workgroup of the octree frame kernel, which it does not
+// use -- a measurement knob that lowers the number of resident wavefronts (160 KB per CU)
+size_t occupancy_probe_lds()
+{
+    static const size_t n = [] { const char *e = std::getenv("VOLLY_PROBE_LDS"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+    return n;
+}
+
 int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size_t frame_offset, const volly_outputs *outs,
                  hipStream_t stream)
 {
@@ -280,7 +288,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
                            s->low, s->d_frames, s->d_ckpt, o);
     } else if (s->is_svo)
-        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
+        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), occupancy_probe_lds(), stream, s->target, s->svo, s->low, s->d_frames,
                            s->d_ckpt, o);
     else if (any_raytrace)
         hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low,

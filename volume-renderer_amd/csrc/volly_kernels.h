@@ -38,6 +38,7 @@
 //                     serial adds per lane and component, twice the checkpoint traffic: measured
 //                     1.4 % slower on config 2, 4 % on config 1)
 //   VK_INDEX24=0      32-bit multiplies for the brick / region index in the regular loop
+//   VK_PACK_ASM=0     let the compiler choose the instructions that pack a cell
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
 //   VK_WAVE_BLOCK=N   N wavefronts (N tiles side by side) per workgroup, each storing its tile
 //                     straight from registers: no LDS, no barrier, 1/N of the workgroup dispatches
@@ -71,6 +72,9 @@
 #endif
 #ifndef VK_SHORT_DIV
 #define VK_SHORT_DIV 1
+#endif
+#ifndef VK_PACK_ASM
+#define VK_PACK_ASM 1
 #endif
 #ifndef VK_INDEX24
 #define VK_INDEX24 1
@@ -326,6 +330,20 @@ __device__ __forceinline__ uint32_t cell_index24(int x, int y, int z, int nx, in
 #endif
 }
 
+// x | y << 10 | z << 20 in two v_lshl_or_b32 (left alone the compiler shifts twice and ORs three
+// values: one instruction more in a loop that is bound by instruction issue)
+__device__ __forceinline__ uint32_t pack_cell(int x, int y, int z)
+{
+#if VK_PACK_ASM
+    uint32_t t, c;
+    asm("v_lshl_or_b32 %0, %1, 10, %2" : "=v"(t) : "v"(y), "v"(x));
+    asm("v_lshl_or_b32 %0, %1, 20, %2" : "=v"(c) : "v"(z), "v"(t));
+    return c;
+#else
+    return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
+#endif
+}
+
 __device__ __forceinline__ bool test_word(uint32_t w_lo, uint32_t w_hi, uint32_t bit)
 {
     uint32_t w = (bit & 32u) ? w_hi : w_lo;
@@ -365,7 +383,7 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
     for (uint32_t iter = 0;; ++iter) {
         float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
         int x = (int)px, y = (int)py, z = (int)pz;       // truncation toward zero, saturating
-        uint32_t c = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
+        uint32_t c = pack_cell(x, y, z);
         if (iter >= g.cap) { h.steps = iter; break; }    // uniform
         uint32_t region = c & 0xFF0FC3F0u;
         if (REGIONS && region != last_region) {

@@ -177,7 +177,7 @@ render_frames_refill(DenseDev target, DenseDev low, const volly_frame_desc *__re
             const bool in_low = phase == 1;
             float px = cx + r.ex, py = cy + r.ey, pz = cz + r.ez;
             int x = (int)px, y = (int)py, z = (int)pz;
-            uint32_t c = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
+            uint32_t c = pack_cell(x, y, z);
             const uint32_t steps = iter - start_iter;
             bool done = steps >= (in_low ? low.cap : target.cap);
             bool hit = false;

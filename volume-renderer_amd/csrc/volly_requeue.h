@@ -56,7 +56,7 @@ __device__ __forceinline__ Hit trace_dense_span(const DenseDev &g, const Ray &r,
     for (uint32_t iter = iter0;; ++iter) {
         float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
         int x = (int)px, y = (int)py, z = (int)pz;
-        uint32_t c = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
+        uint32_t c = pack_cell(x, y, z);
         if (iter >= g.cap) { h.steps = iter; break; }    // uniform
         if (iter >= iter_end) { h.steps = iter; parked = true; break; }   // uniform: everyone still here is parked
         uint32_t region = c & 0xFF0FC3F0u;
