@@ -243,9 +243,10 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     o.pt_end = outs->pt_end ? outs->pt_end + 3 * px : nullptr;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (s->profiling) {
+    if (s->profiling) {                                   // the pair belongs to the scene from here on (destroy() frees it)
         HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
+        if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(VOLLY_E_HIP, "render: hipEventCreate failed"); }
+        s->events.emplace_back(e0, e1);
         HIP_TRY(hipEventRecord(e0, stream));
     }
     dim3 grid((unsigned)((tw + vk::kBlockW - 1) / vk::kBlockW), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
@@ -297,10 +298,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
                            s->d_ckpt, o);
     HIP_TRY(hipGetLastError());
-    if (s->profiling) {
-        HIP_TRY(hipEventRecord(e1, stream));
-        s->events.emplace_back(e0, e1);
-    }
+    if (s->profiling) HIP_TRY(hipEventRecord(e1, stream));
     return VOLLY_OK;
 }
 
@@ -542,12 +540,13 @@ int volly_gpu_kernel_time(volly_gpu_scene *scene, double *ms_total, int *launche
     DeviceGuard g(scene->device);
     double total = 0.0;
     int n = 0;
-    for (auto &e : scene->events) {
-        HIP_TRY(hipEventSynchronize(e.second));
+    for (auto &e : scene->events) {                        // a pair whose launch failed half way is dropped, not counted
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
-        total += ms;
-        ++n;
+        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+            total += ms;
+            ++n;
+        } else
+            (void)hipGetLastError();
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
