@@ -249,7 +249,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         s->events.emplace_back(e0, e1);
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    dim3 grid((unsigned)((tw + vk::kBlockW - 1) / vk::kBlockW), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
+    dim3 grid((unsigned)((tw + vk::kBlockW * vk::kTilesPerWave - 1) / (vk::kBlockW * vk::kTilesPerWave)), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
     bool any_raytrace = false;
     for (int i = 0; i < n; ++i) any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
     if (s->requeue && !any_raytrace) {

@@ -40,6 +40,9 @@
 //   VK_INDEX24=0      32-bit multiplies for the brick / region index in the regular loop
 //   VK_PACK_ASM=0     let the compiler choose the instructions that pack a cell
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
+//   VK_TILES_PER_WAVE=K  a wavefront renders K tiles one after the other and asks for the next
+//                     tile's checkpoint early (measured 15-35 % slower for K = 2, 4, 8)
+//   VK_PROBE_WAVES=N  measurement only: N resident wavefronts per SIMD (register padding)
 //   VK_WAVE_BLOCK=N   N wavefronts (N tiles side by side) per workgroup, each storing its tile
 //                     straight from registers: no LDS, no barrier, 1/N of the workgroup dispatches
 //   VK_WAVE_BLOCK=0   four wavefronts (a 32x8 pixel block) per workgroup with the output rows
@@ -73,6 +76,9 @@
 #ifndef VK_SHORT_DIV
 #define VK_SHORT_DIV 1
 #endif
+#ifndef VK_TILES_PER_WAVE
+#define VK_TILES_PER_WAVE 1
+#endif
 #ifndef VK_PACK_ASM
 #define VK_PACK_ASM 1
 #endif
@@ -91,6 +97,12 @@ constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
 constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pixels of a row (at most kCkpt - 1 adds per lane)
 constexpr int kBlockW = VK_WAVE_BLOCK ? 8 * VK_WAVE_BLOCK : 32;   // workgroup covers VK_WAVE_BLOCK tiles of 8 x 8 pixels side by side
 constexpr int kBlockH = 8;
+constexpr int kTilesPerWave = VK_WAVE_BLOCK ? VK_TILES_PER_WAVE : 1;   // tiles a wavefront renders one after the other (side by side in x)
+#ifdef VK_PROBE_WAVES            // measurement only: cap the resident wavefronts per SIMD through the register allocation
+#define VK_FRAME_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(VK_PROBE_WAVES, VK_PROBE_WAVES)))
+#else
+#define VK_FRAME_WAVES_ATTR
+#endif
 constexpr int kThreads = 256;
 constexpr int kFrameThreads = VK_WAVE_BLOCK ? 64 * VK_WAVE_BLOCK : 256;   // workgroup size of render_frames
 constexpr int kTopNodes = VK_LDS_TOP ? 585 : 1;   // octree levels 0..3 (1 + 8 + 64 + 512 nodes) staged in LDS
@@ -645,11 +657,91 @@ direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames,
     }
 }
 
+// what one ray leaves behind (RaycastReport + the pixel, main.cpp:81-86,269-271)
+struct PixelOut {
+    uint32_t rgba = 255u, hit = VOLLY_MISS_INDEX, slo = 0, shi = 0;
+    float depth = __uint_as_float(0x7F800000u);
+    float ex = 0.f, ey = 0.f, ez = 0.f;                  // RaycastReport::ptEnd
+};
+
+// the six direction sums of a pixel's checkpoint (target xyz, low xyz)
+struct Ckpt { float v[6]; };
+
+__device__ __forceinline__ Ckpt load_checkpoint(const float *__restrict__ ckpt, const volly_frame_desc &fd, int f, int xrel, int yrel)
+{
+    // checkpoint scratch of one launch stays below 2^31 floats (render_chunk): 32-bit indices
+    const uint32_t groups = (uint32_t)(fd.tile_w + kCkpt - 1) / (uint32_t)kCkpt;
+    const uint32_t cs = (uint32_t)fd.tile_h;
+    const float *c = ckpt + (((uint32_t)f * groups + (uint32_t)xrel / (uint32_t)kCkpt) * 6u * cs + (uint32_t)yrel);
+    Ckpt k;
+    #pragma unroll
+    for (int i = 0; i < 6; ++i) k.v[i] = c[(uint32_t)i * cs];
+    return k;
+}
+
+// main.cpp:256-272 for one pixel, from its checkpoint
+template <bool SVO, bool RAYTRACE>
+__device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const SvoDev &svo, const DenseDev &low, const volly_frame_desc &fd,
+                                                 const uint2 *top, const Ckpt &k, int xrel)
+{
+    PixelOut o;
+    float hx = k.v[0], hy = k.v[1], hz = k.v[2], lx = k.v[3], ly = k.v[4], lz = k.v[5];
+    const int extra = xrel % kCkpt;
+    for (int i = 0; i < extra; ++i) {                     // main.cpp:282-283
+        hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];
+        lx = lx + fd.xdiff_lo[0]; ly = ly + fd.xdiff_lo[1]; lz = lz + fd.xdiff_lo[2];
+    }
+    const float hw = normalize_w0(hx, hy, hz);            // main.cpp:260
+    const Ray ray_hi = make_ray(hx, hy, hz);
+    if constexpr (!SVO && RAYTRACE) {
+        if (fd.flags & VOLLY_FRAME_RAYTRACE) {            // main.cpp:274-278 (commented call site)
+            Hit prim;
+            const V4 col = raytrace<3>(target, fd.origin_hi[0], fd.origin_hi[1], fd.origin_hi[2], V4{hx, hy, hz, hw}, &prim);
+            const uint32_t tr = (uint32_t)(fminf(fmaxf(col.x, 0.0f), 1.0f) * 255.f) & 0xFFu;
+            const uint32_t tg = (uint32_t)(fminf(fmaxf(col.y, 0.0f), 1.0f) * 255.f) & 0xFFu;
+            const uint32_t tb = (uint32_t)(fminf(fmaxf(col.z, 0.0f), 1.0f) * 255.f) & 0xFFu;
+            o.rgba = 255u | (tr << 8) | (tg << 16) | (tb << 24);
+            o.shi = prim.steps;
+            o.hit = prim.index;
+            o.ex = prim.cx; o.ey = prim.cy; o.ez = prim.cz;
+            if (prim.index != VOLLY_MISS_INDEX) {
+                float ddx = prim.cx - fd.origin_hi[0], ddy = prim.cy - fd.origin_hi[1], ddz = prim.cz - fd.origin_hi[2];
+                o.depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
+            }
+            return o;
+        }
+    }
+    (void)hw;
+
+    float sx, sy, sz;                                     // start of the target-grid pass
+    if (fd.flags & VOLLY_FRAME_NAIVE) {                   // main.cpp:261
+        sx = fd.origin_hi[0]; sy = fd.origin_hi[1]; sz = fd.origin_hi[2];
+    } else {                                              // raycast_beamOpt, main.cpp:163-166
+        normalize_w0(lx, ly, lz);
+        const Ray ray_lo = make_ray(lx, ly, lz);
+        Hit lo = trace_dense(low, ray_lo, fd.origin_lo[0], fd.origin_lo[1], fd.origin_lo[2]);
+        o.slo = lo.steps;
+        sx = fd.scale_lo_to_hi[0] * lo.cx; sy = fd.scale_lo_to_hi[1] * lo.cy; sz = fd.scale_lo_to_hi[2] * lo.cz;
+    }
+
+    Hit hi = SVO ? trace_svo(svo, top, ray_hi, sx, sy, sz) : trace_dense(target, ray_hi, sx, sy, sz);
+    o.shi = hi.steps;
+    o.hit = hi.index;
+    o.ex = hi.cx; o.ey = hi.cy; o.ez = hi.cz;
+    if (hi.index != VOLLY_MISS_INDEX) {
+        uint2 vox = SVO ? svo.leaves[hi.payload] : target.vox[hi.payload];
+        o.rgba = shade(vox);
+        float ddx = hi.cx - fd.origin_hi[0], ddy = hi.cy - fd.origin_hi[1], ddz = hi.cz - fd.origin_hi[2];
+        o.depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
+    }
+    return o;
+}
+
 // ---- the frame kernel: main.cpp:256-272 for every pixel of the sub-rectangle --
 // RAYTRACE: the instantiation that can also serve VOLLY_FRAME_RAYTRACE frames (dense targets);
 // it needs 96 VGPRs, so frames of the live path never run through it.
 template <bool SVO, bool RAYTRACE = false>
-__global__ void __launch_bounds__(kFrameThreads)
+__global__ void __launch_bounds__(kFrameThreads) VK_FRAME_WAVES_ATTR
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
               const float *__restrict__ ckpt, OutDev out)
 {
@@ -665,7 +757,9 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
     }
 
     const int f = blockIdx.z;
-    const volly_frame_desc fd = frames[f];                // uniform: lives in SGPRs
+    // uniform, read with scalar loads where it is used: a by-value copy keeps ~50 scalar registers
+    // busy for the whole kernel, and measured 0.5-1 % slower (profiles/r01_ab/ab_tiles_per_wave_c2.log, "new" vs "base")
+    const volly_frame_desc &fd = frames[f];
 #if VK_XCD_REMAP
     // workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD): renumber
     // them so that each XCD renders one contiguous range of pixel blocks of the frame
@@ -685,94 +779,50 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
     const int px_in_block = wave * kTile + (lane & 7);    // a wavefront covers an 8x8 tile
     const int py_in_block = lane >> 3;
 #endif
-    const int xrel = bx * kBlockW + px_in_block;
     const int yrel = by * kBlockH + py_in_block;
-    const bool active = (xrel < fd.tile_w) & (yrel < fd.tile_h);
-
-    uint32_t o_rgba = 255u, o_hit = VOLLY_MISS_INDEX, o_slo = 0, o_shi = 0;
-    float o_depth = __uint_as_float(0x7F800000u);
-    float o_ex = 0.f, o_ey = 0.f, o_ez = 0.f;             // RaycastReport::ptEnd
-
-    if (active) {
-        // checkpoint scratch of one launch stays below 2^31 floats (render_chunk): 32-bit indices
-        const uint32_t groups = (uint32_t)(fd.tile_w + kCkpt - 1) / (uint32_t)kCkpt;
-        const uint32_t cs = (uint32_t)fd.tile_h;
-        const float *c = ckpt + (((uint32_t)f * groups + (uint32_t)xrel / (uint32_t)kCkpt) * 6u * cs + (uint32_t)yrel);
-        float hx = c[0], hy = c[cs], hz = c[2 * cs], lx = c[3 * cs], ly = c[4 * cs], lz = c[5 * cs];
-        const int extra = xrel % kCkpt;
-        for (int i = 0; i < extra; ++i) {                 // main.cpp:282-283
-            hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];
-            lx = lx + fd.xdiff_lo[0]; ly = ly + fd.xdiff_lo[1]; lz = lz + fd.xdiff_lo[2];
-        }
-        const float hw = normalize_w0(hx, hy, hz);        // main.cpp:260
-        const Ray ray_hi = make_ray(hx, hy, hz);
-        bool traced = false;
-        if constexpr (!SVO && RAYTRACE) {
-            if (fd.flags & VOLLY_FRAME_RAYTRACE) {        // main.cpp:274-278 (commented call site)
-                Hit prim;
-                const V4 col = raytrace<3>(target, fd.origin_hi[0], fd.origin_hi[1], fd.origin_hi[2], V4{hx, hy, hz, hw}, &prim);
-                const uint32_t tr = (uint32_t)(fminf(fmaxf(col.x, 0.0f), 1.0f) * 255.f) & 0xFFu;
-                const uint32_t tg = (uint32_t)(fminf(fmaxf(col.y, 0.0f), 1.0f) * 255.f) & 0xFFu;
-                const uint32_t tb = (uint32_t)(fminf(fmaxf(col.z, 0.0f), 1.0f) * 255.f) & 0xFFu;
-                o_rgba = 255u | (tr << 8) | (tg << 16) | (tb << 24);
-                o_shi = prim.steps;
-                o_hit = prim.index;
-                o_ex = prim.cx; o_ey = prim.cy; o_ez = prim.cz;
-                if (prim.index != VOLLY_MISS_INDEX) {
-                    float ddx = prim.cx - fd.origin_hi[0], ddy = prim.cy - fd.origin_hi[1], ddz = prim.cz - fd.origin_hi[2];
-                    o_depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
-                }
-                traced = true;
-            }
-        }
-        if (!traced) {
-
-        float sx, sy, sz;                                 // start of the target-grid pass
-        if (fd.flags & VOLLY_FRAME_NAIVE) {               // main.cpp:261
-            sx = fd.origin_hi[0]; sy = fd.origin_hi[1]; sz = fd.origin_hi[2];
-        } else {                                          // raycast_beamOpt, main.cpp:163-166
-            normalize_w0(lx, ly, lz);
-            const Ray ray_lo = make_ray(lx, ly, lz);
-            Hit lo = trace_dense(low, ray_lo, fd.origin_lo[0], fd.origin_lo[1], fd.origin_lo[2]);
-            o_slo = lo.steps;
-            sx = fd.scale_lo_to_hi[0] * lo.cx; sy = fd.scale_lo_to_hi[1] * lo.cy; sz = fd.scale_lo_to_hi[2] * lo.cz;
-        }
-
-        Hit hi = SVO ? trace_svo(svo, top, ray_hi, sx, sy, sz) : trace_dense(target, ray_hi, sx, sy, sz);
-        o_shi = hi.steps;
-        o_hit = hi.index;
-        o_ex = hi.cx; o_ey = hi.cy; o_ez = hi.cz;
-        if (hi.index != VOLLY_MISS_INDEX) {
-            uint2 vox = SVO ? svo.leaves[hi.payload] : target.vox[hi.payload];
-            o_rgba = shade(vox);
-            float ddx = hi.cx - fd.origin_hi[0], ddy = hi.cy - fd.origin_hi[1], ddz = hi.cz - fd.origin_hi[2];
-            o_depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
-        }
-        }
-    }
 
 #if VK_WAVE_BLOCK
-    if (active) {                                         // eight 32-byte row segments per store instruction
-        const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
-        if (out.rgba8) out.rgba8[p] = o_rgba;
-        if (out.hit_index) out.hit_index[p] = o_hit;
-        if (out.steps_lo) out.steps_lo[p] = o_slo;
-        if (out.steps_hi) out.steps_hi[p] = o_shi;
-        if (out.depth) out.depth[p] = o_depth;
-        if (out.pt_end) { out.pt_end[3 * p] = o_ex; out.pt_end[3 * p + 1] = o_ey; out.pt_end[3 * p + 2] = o_ez; }
+    // kTilesPerWave > 1 (a measured and rejected variant): a wavefront renders
+    // that many tiles side by side, one after the other, and asks for the next tile's checkpoint
+    // before it marches through the current one.
+    const int x_first = bx * (kBlockW * kTilesPerWave) + px_in_block;
+    Ckpt next{};
+    if (x_first < fd.tile_w && yrel < fd.tile_h) next = load_checkpoint(ckpt, fd, f, x_first, yrel);
+    #pragma unroll 1
+    for (int t = 0; t < kTilesPerWave; ++t) {
+        const int xrel = x_first + t * kBlockW;
+        if (xrel - px_in_block >= fd.tile_w) break;       // uniform: the tile lies right of the sub-rectangle
+        const bool active = (xrel < fd.tile_w) & (yrel < fd.tile_h);
+        const Ckpt cur = next;
+        if (kTilesPerWave > 1 && t + 1 < kTilesPerWave && xrel + kBlockW < fd.tile_w && yrel < fd.tile_h)
+            next = load_checkpoint(ckpt, fd, f, xrel + kBlockW, yrel);
+        if (active) {                                     // eight 32-byte row segments per store instruction
+            const PixelOut o = render_pixel<SVO, RAYTRACE>(target, svo, low, fd, top, cur, xrel);
+            const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
+            if (out.rgba8) out.rgba8[p] = o.rgba;
+            if (out.hit_index) out.hit_index[p] = o.hit;
+            if (out.steps_lo) out.steps_lo[p] = o.slo;
+            if (out.steps_hi) out.steps_hi[p] = o.shi;
+            if (out.depth) out.depth[p] = o.depth;
+            if (out.pt_end) { out.pt_end[3 * p] = o.ex; out.pt_end[3 * p + 1] = o.ey; out.pt_end[3 * p + 2] = o.ez; }
+        }
     }
 #else
+    const int xrel = bx * kBlockW + px_in_block;
+    const bool active = (xrel < fd.tile_w) & (yrel < fd.tile_h);
+    PixelOut o;
+    if (active) o = render_pixel<SVO, RAYTRACE>(target, svo, low, fd, top, load_checkpoint(ckpt, fd, f, xrel, yrel), xrel);
     // framebuffer writeback: through LDS so that every store instruction writes
     // whole 128-byte row segments (main.cpp:269-271 writes data_stream[x + y*W])
     if (active && out.pt_end) {
         const size_t q = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
-        out.pt_end[3 * q] = o_ex; out.pt_end[3 * q + 1] = o_ey; out.pt_end[3 * q + 2] = o_ez;
+        out.pt_end[3 * q] = o.ex; out.pt_end[3 * q + 1] = o.ey; out.pt_end[3 * q + 2] = o.ez;
     }
-    stage[0][py_in_block][px_in_block] = o_rgba;
-    stage[1][py_in_block][px_in_block] = o_hit;
-    stage[2][py_in_block][px_in_block] = o_slo;
-    stage[3][py_in_block][px_in_block] = o_shi;
-    stage[4][py_in_block][px_in_block] = __float_as_uint(o_depth);
+    stage[0][py_in_block][px_in_block] = o.rgba;
+    stage[1][py_in_block][px_in_block] = o.hit;
+    stage[2][py_in_block][px_in_block] = o.slo;
+    stage[3][py_in_block][px_in_block] = o.shi;
+    stage[4][py_in_block][px_in_block] = __float_as_uint(o.depth);
     __syncthreads();
     const int wx = threadIdx.x & 31, wy = threadIdx.x >> 5;
     const int oxr = bx * kBlockW + wx, oyr = by * kBlockH + wy;
