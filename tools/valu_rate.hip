@@ -79,6 +79,30 @@ __global__ void __launch_bounds__(256) k_pk_add_f32(float *out, int iters, float
     out[blockIdx.x * 256 + threadIdx.x] = p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
 
+// the same chains with part of the wavefront switched off: does a vector instruction cost less
+// when 32 consecutive lanes (or every other lane) are inactive?
+#define KERNEL_MASKED(name, COND, DECL, STEP)                                             \
+    __global__ void __launch_bounds__(256) name(float *out, int iters, float seed)        \
+    {                                                                                     \
+        DECL;                                                                             \
+        const int lane = threadIdx.x & 63;                                                \
+        if (COND) {                                                                       \
+            for (int i = 0; i < iters; ++i) {                                             \
+                _Pragma("unroll") for (int r = 0; r < REP / 8; ++r) { STEP; }             \
+            }                                                                             \
+        }                                                                                 \
+        out[blockIdx.x * 256 + threadIdx.x] = sink(a0, a1, a2, a3, a4, a5, a6, a7);       \
+    }
+KERNEL_MASKED(k_add_f32_low32, lane < 32, F8, ALL(ADDF))
+KERNEL_MASKED(k_add_f32_low16, lane < 16, F8, ALL(ADDF))
+KERNEL_MASKED(k_add_f32_even, (lane & 1) == 0, F8, ALL(ADDF))
+KERNEL_MASKED(k_add_f32_1of4rows, (lane & 8) == 0 && lane < 32, F8, ALL(ADDF))
+KERNEL_MASKED(k_floor_f32_low32, lane < 32, F8, ALL(FLOORF))
+KERNEL_MASKED(k_floor_f32_low16, lane < 16, F8, ALL(FLOORF))
+KERNEL_MASKED(k_floor_f32_even, (lane & 1) == 0, F8, ALL(FLOORF))
+KERNEL_MASKED(k_cvt_low32, lane < 32, F8, ALL(CVTI))
+KERNEL_MASKED(k_lshl_or_low32, lane < 32, U8, ALL(LSHLOR))
+
 template <class K> void run(const char *name, K kernel, float *out, double ghz)
 {
     const int blocks = 256 * 8, iters = 2000;             // 8 blocks of 4 waves per CU = 8 waves per SIMD
@@ -106,5 +130,7 @@ int main()
     RUN(k_add_f32); RUN(k_mul_f32); RUN(k_fma_f32); RUN(k_floor_f32); RUN(k_min3_f32); RUN(k_cvt_i32_f32); RUN(k_rcp_f32); RUN(k_cmp_f32);
     RUN(k_and_b32); RUN(k_lshl_b32); RUN(k_or3_b32); RUN(k_lshl_or_b32); RUN(k_add_u32); RUN(k_cmp_u32); RUN(k_cndmask); RUN(k_mov_b32);
     RUN(k_mul_u24); RUN(k_bfe_u32); RUN(k_pk_add_f32);
+    RUN(k_add_f32_low32); RUN(k_add_f32_low16); RUN(k_add_f32_even); RUN(k_add_f32_1of4rows);
+    RUN(k_floor_f32_low32); RUN(k_floor_f32_low16); RUN(k_floor_f32_even); RUN(k_cvt_low32); RUN(k_lshl_or_low32);
     return 0;
 }
