@@ -75,7 +75,22 @@ examples/volly_headless: examples/volly_headless.cpp $(PKG)/host/volly_state.h $
 	$(CXX) -O2 -std=c++17 $(FPFLAGS) -Wall -Wextra -o $@ examples/volly_headless.cpp \
 	    -L$(LIBDIR) -lvolly_host -lvolly_gpu -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath-link,/opt/rocm/lib
 
+# Host side of both libraries under AddressSanitizer (clang's runtime; device code is left
+# alone: GPU sanitizers are not available on the pool) plus a driver over the whole C-ABI.
+# Run build/san/gpu_sanitize_driver assets on a box with an MI355X.
+SANDIR := build/san
+CLANGXX ?= /opt/rocm/lib/llvm/bin/clang++
+sanitize-gpu:
+	@mkdir -p $(SANDIR)/lib
+	$(HIPCC) --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared $(FPFLAGS) -fno-slp-vectorize -Xarch_host -fsanitize=address \
+	    -Xarch_host -fno-omit-frame-pointer -Iinclude -o $(SANDIR)/lib/libvolly_gpu.so $(GPU_SRC)
+	$(CLANGXX) -O1 -g -std=c++17 -fPIC -shared -pthread $(FPFLAGS) -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer -Iinclude \
+	    -o $(SANDIR)/lib/libvolly_host.so $(HOST_SRC)
+	$(CLANGXX) -O1 -g -std=c++17 $(FPFLAGS) -fsanitize=address -fno-gpu-sanitize -fno-omit-frame-pointer -Iinclude -I/opt/rocm/include \
+	    -D__HIP_PLATFORM_AMD__ -o $(SANDIR)/gpu_sanitize_driver tests/gpu_sanitize_driver.cpp \
+	    -L$(SANDIR)/lib -lvolly_host -lvolly_gpu -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/lib' -Wl,-rpath,/opt/rocm/lib
+
 clean:
 	rm -rf $(LIBDIR) oracle/libvolly_oracle.so oracle/_ref examples/volly_headless tools/exhaustive_math tools/valu_rate
 
-.PHONY: all gpu host oracle ref examples tools variants clean
+.PHONY: sanitize-gpu all gpu host oracle ref examples tools variants clean
