@@ -227,10 +227,16 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         HIP_TRY(hipMalloc((void **)&s->d_ckpt, need * sizeof(float)));
         s->ckpt_floats = need;
     }
-    HIP_TRY(hipMemcpyAsync(s->d_frames, frames, sizeof(volly_frame_desc) * (size_t)n, hipMemcpyHostToDevice, stream));
-
-    hipLaunchKernelGGL(vk::direction_checkpoints, dim3((unsigned)((th + 63) / 64), (unsigned)n, 6), dim3(64), 0, stream,
-                       s->d_frames, n, s->d_ckpt);
+    const dim3 pre_grid((unsigned)((th + 63) / 64), (unsigned)n, 6);
+    if (n <= vk::kInlineFrames) {                         // descriptors as kernel arguments: no copy ahead of the pre-pass
+        vk::FrameBatch batch;
+        std::memcpy(batch.f, frames, sizeof(volly_frame_desc) * (size_t)n);
+        std::memset(batch.f + n, 0, sizeof(volly_frame_desc) * (size_t)(vk::kInlineFrames - n));
+        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, n, s->d_frames, s->d_ckpt);
+    } else {
+        HIP_TRY(hipMemcpyAsync(s->d_frames, frames, sizeof(volly_frame_desc) * (size_t)n, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(vk::direction_checkpoints, pre_grid, dim3(64), 0, stream, s->d_frames, n, s->d_ckpt);
+    }
     HIP_TRY(hipGetLastError());
 
     const size_t px = (size_t)tw * th * frame_offset;

@@ -625,15 +625,9 @@ __device__ V4 raytrace(const DenseDev &g, float sx, float sy, float sz, V4 dir, 
 // A thread walks its chain -- y adds down to its row, then along the row -- and stores the
 // running sum every kCkpt pixels.  ckpt layout: [frame][column group][component][row], so
 // the 64 rows of a workgroup store 256 contiguous bytes.
-__global__ void __launch_bounds__(64)
-direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames, float *__restrict__ ckpt)
+__device__ __forceinline__ void checkpoint_chain(const volly_frame_desc &fd, int f, int comp, int yrel, float *__restrict__ ckpt)
 {
-    const int f = blockIdx.y;
-    if (f >= n_frames) return;
-    const int comp = blockIdx.z;                          // 0..2 target xyz, 3..5 low xyz
-    const volly_frame_desc &fd = frames[f];
     const int tile_w = fd.tile_w, tile_h = fd.tile_h, x0 = fd.x0;
-    const int yrel = blockIdx.x * blockDim.x + threadIdx.x;
     if (yrel >= tile_h) return;
     const int y = fd.y0 + yrel;
     const int lo = comp >= 3, k = comp - 3 * lo;
@@ -655,6 +649,39 @@ direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames,
         #pragma unroll
         for (int i = 0; i < kCkpt; ++i) v = v + dx;
     }
+}
+
+__global__ void __launch_bounds__(64)
+direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames, float *__restrict__ ckpt)
+{
+    const int f = blockIdx.y;
+    if (f >= n_frames) return;
+    checkpoint_chain(frames[f], f, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, ckpt);
+}
+
+// The same with the frame descriptors of a small batch travelling as kernel arguments: no
+// host-to-device copy ahead of the pre-pass (4 us + a launch gap per call).  The kernel also
+// leaves the descriptors in frames_out, where the frame kernel reads them.
+constexpr int kInlineFrames = 16;
+struct FrameBatch { volly_frame_desc f[kInlineFrames]; };
+static_assert(sizeof(FrameBatch) <= 3072, "kernel arguments are limited to 4 KB");
+
+__global__ void __launch_bounds__(64)
+direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *__restrict__ frames_out, float *__restrict__ ckpt)
+{
+    const int f = blockIdx.y;
+    if (f >= n_frames) return;
+    // the batch is the first argument: read it where it lies in the kernel-argument segment
+    // (indexing the by-value copy with a run-time index would move it to scratch memory)
+    const volly_frame_desc *args = (const volly_frame_desc *)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)batch;
+    if (blockIdx.x == 0 && blockIdx.z == 0) {
+        constexpr unsigned words = sizeof(volly_frame_desc) / 4;
+        const uint32_t *src = (const uint32_t *)(args + f);
+        uint32_t *dst = (uint32_t *)(frames_out + f);
+        for (unsigned w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+    }
+    checkpoint_chain(args[f], f, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, ckpt);
 }
 
 // what one ray leaves behind (RaycastReport + the pixel, main.cpp:81-86,269-271)
