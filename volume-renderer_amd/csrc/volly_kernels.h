@@ -39,6 +39,7 @@
 //                     1.4 % slower on config 2, 4 % on config 1)
 //   VK_INDEX24=0      32-bit multiplies for the brick / region index in the regular loop
 //   VK_PACK_ASM=0     let the compiler choose the instructions that pack a cell
+//   VK_ASM_QUIET=0    the compiled region loop only (no assembly loop for the quiet steps)
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
 //   VK_TILES_PER_WAVE=K  a wavefront renders K tiles one after the other and asks for the next
 //                     tile's checkpoint early (measured 15-35 % slower for K = 2, 4, 8)
@@ -78,6 +79,9 @@
 #endif
 #ifndef VK_TILES_PER_WAVE
 #define VK_TILES_PER_WAVE 1
+#endif
+#ifndef VK_ASM_QUIET
+#define VK_ASM_QUIET 1
 #endif
 #ifndef VK_PACK_ASM
 #define VK_PACK_ASM 1
@@ -442,13 +446,132 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
     return h;
 }
 
+// trace_dense_regular<true> with the quiet steps in assembly (VK_ASM_QUIET).  Measured: in 52 % of
+// the wave-steps of the headline workload no lane changes its 16^3 region or sits in a region
+// with voxels (profiles/r01_ab/count_quiet_steps.log); such a step needs no per-lane test at all.
+// The assembly loop runs those steps back to back -- 29 vector and 5 scalar instructions each,
+// against 35 and ~20 in the compiled loop -- and hands the first step that needs attention (or
+// reaches the iteration cap), with its sample point, cell and packed cell already computed, to
+// the same per-lane code as before.  `watch` is the lane's region key while that region is known
+// to be empty, else 0xFFFFFFFF, which no key equals.
+__device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
+    uint32_t last_brick = 0xFFFFFFFFu, w_lo = 0, w_hi = 0;
+    uint32_t last_region = 0xFFFFFFFFu, r_lo = 0, r_hi = 0, r_any = 0;
+    uint32_t watch = 0xFFFFFFFFu;
+    uint32_t live = 1;
+    // The iteration number is the same in every lane still in the loop.  The compiler will not
+    // keep a loop-carried value of a divergent loop in a scalar register ("illegal VGPR to SGPR
+    // copy"), so it lives in m0, which nothing else in these kernels uses (no LDS, no indexed
+    // registers, no messages), and is read into a scalar register where C++ needs it.
+    const uint32_t cap = g.cap;
+    asm volatile("s_mov_b32 m0, 0");
+    for (;;) {
+        float px, py, pz, t0, t1, t2;
+        int x, y, z;
+        uint32_t c;
+        asm volatile(
+            "1:\n\t"
+            "v_add_f32 %[px], %[cx], %[ex]\n\t"
+            "v_add_f32 %[py], %[cy], %[ey]\n\t"
+            "v_add_f32 %[pz], %[cz], %[ez]\n\t"
+            "v_cvt_i32_f32 %[x], %[px]\n\t"
+            "v_cvt_i32_f32 %[y], %[py]\n\t"
+            "v_cvt_i32_f32 %[z], %[pz]\n\t"
+            "v_lshl_or_b32 %[c], %[y], 10, %[x]\n\t"
+            "v_lshl_or_b32 %[c], %[z], 20, %[c]\n\t"
+            "v_and_b32 %[t0], 0xff0fc3f0, %[c]\n\t"
+            "v_cmp_ne_u32 vcc, %[t0], %[watch]\n\t"
+            "s_cbranch_vccnz 2f\n\t"
+            "s_cmp_ge_u32 m0, %[cap]\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "v_floor_f32 %[t0], %[px]\n\t"
+            "v_floor_f32 %[t1], %[py]\n\t"
+            "v_floor_f32 %[t2], %[pz]\n\t"
+            "v_add_f32 %[t0], %[t0], %[hx]\n\t"
+            "v_add_f32 %[t1], %[t1], %[hy]\n\t"
+            "v_add_f32 %[t2], %[t2], %[hz]\n\t"
+            "v_sub_f32 %[t0], %[t0], %[cx]\n\t"
+            "v_sub_f32 %[t1], %[t1], %[cy]\n\t"
+            "v_sub_f32 %[t2], %[t2], %[cz]\n\t"
+            "v_mul_f32 %[t0], %[t0], %[ix]\n\t"
+            "v_mul_f32 %[t1], %[t1], %[iy]\n\t"
+            "v_mul_f32 %[t2], %[t2], %[iz]\n\t"
+            "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"
+            "v_mul_f32 %[t1], %[t0], %[dx]\n\t"
+            "v_mul_f32 %[t2], %[t0], %[dy]\n\t"
+            "v_mul_f32 %[t0], %[t0], %[dz]\n\t"
+            "v_add_f32 %[cx], %[t1], %[cx]\n\t"
+            "v_add_f32 %[cy], %[t2], %[cy]\n\t"
+            "v_add_f32 %[cz], %[t0], %[cz]\n\t"
+            "s_add_u32 m0, m0, 1\n\t"
+            "s_branch 1b\n"
+            "2:"
+            : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz),
+              [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [c] "=&v"(c),
+              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+            : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
+              [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
+              [watch] "v"(watch), [cap] "s"(cap)
+            : "vcc", "scc");
+        uint32_t iter;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
+        if (iter >= cap) { h.steps = iter; break; }      // uniform
+        const uint32_t region = c & 0xFF0FC3F0u;
+        if (region != last_region) {
+            bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
+            if (inside) {
+                uint64_t bits = g.occ2[cell_index24(x >> 4, y >> 4, z >> 4, g.nrx, g.nry)];
+                r_lo = (uint32_t)bits;
+                r_hi = (uint32_t)(bits >> 32);
+                r_any = (r_lo | r_hi) != 0u;
+                last_region = region;
+                watch = r_any ? 0xFFFFFFFFu : region;
+            } else {                                     // left the grid: main.cpp:126-135
+                r_any = 0;
+                live = 0;
+                h.steps = iter;
+            }
+        }
+        if (r_any && test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {      // the brick holds voxels
+            uint32_t brick = c & 0xFFCFF3FCu;
+            if (brick != last_brick) {
+                uint64_t bits = g.occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
+                w_lo = (uint32_t)bits;
+                w_hi = (uint32_t)(bits >> 32);
+                last_brick = brick;
+            }
+            if (test_word(w_lo, w_hi, gather_bits(c & 0x00300C03u))) {   // main.cpp:139-142
+                live = 0;
+                h.steps = iter + 1;
+                h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
+                h.payload = h.index;
+            }
+        }
+        if (!live) break;
+        advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
+        asm volatile("s_add_u32 m0, m0, 1" : : : "scc");
+    }
+    return h;
+}
+
 __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
 #if VK_FAST_DDA && !VK_AOS_SAMPLE
     // one path per wavefront, so the two loops never run interleaved in a wave
     if (grid_is_regular(g) && __all(ray_is_regular(r))) {
         // the 16^3 region level is chosen per grid at upload (DenseDev::use_regions)
+#if VK_ASM_QUIET
+        if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regular_asm(g, r, ox, oy, oz);
+#else
         if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regular<true>(g, r, ox, oy, oz);
+#endif
         return trace_dense_regular<false>(g, r, ox, oy, oz);
     }
 #endif
