@@ -464,7 +464,7 @@ __device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const 
     if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
     uint32_t last_brick = 0xFFFFFFFFu, w_lo = 0, w_hi = 0;
     uint32_t last_region = 0xFFFFFFFFu, r_lo = 0, r_hi = 0, r_any = 0;
-    uint32_t watch = 0xFFFFFFFFu;
+    uint32_t watch = 0xFFFFFFFFu, wmask = 0xFF0FC3F0u;
     uint32_t live = 1;
     // The iteration number is the same in every lane still in the loop.  The compiler will not
     // keep a loop-carried value of a divergent loop in a scalar register ("illegal VGPR to SGPR
@@ -486,7 +486,7 @@ __device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const 
             "v_cvt_i32_f32 %[z], %[pz]\n\t"
             "v_lshl_or_b32 %[c], %[y], 10, %[x]\n\t"
             "v_lshl_or_b32 %[c], %[z], 20, %[c]\n\t"
-            "v_and_b32 %[t0], 0xff0fc3f0, %[c]\n\t"
+            "v_and_b32 %[t0], %[wmask], %[c]\n\t"
             "v_cmp_ne_u32 vcc, %[t0], %[watch]\n\t"
             "s_cbranch_vccnz 2f\n\t"
             "s_cmp_ge_u32 m0, %[cap]\n\t"
@@ -518,7 +518,7 @@ __device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const 
               [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
             : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
               [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-              [watch] "v"(watch), [cap] "s"(cap)
+              [watch] "v"(watch), [wmask] "v"(wmask), [cap] "s"(cap)
             : "vcc", "scc");
         uint32_t iter;
         asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
@@ -532,26 +532,32 @@ __device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const 
                 r_hi = (uint32_t)(bits >> 32);
                 r_any = (r_lo | r_hi) != 0u;
                 last_region = region;
-                watch = r_any ? 0xFFFFFFFFu : region;
+                watch = region;                          // quiet until the lane leaves this region ...
+                wmask = 0xFF0FC3F0u;
             } else {                                     // left the grid: main.cpp:126-135
                 r_any = 0;
                 live = 0;
                 h.steps = iter;
             }
         }
-        if (r_any && test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {      // the brick holds voxels
-            uint32_t brick = c & 0xFFCFF3FCu;
-            if (brick != last_brick) {
-                uint64_t bits = g.occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
-                w_lo = (uint32_t)bits;
-                w_hi = (uint32_t)(bits >> 32);
-                last_brick = brick;
-            }
-            if (test_word(w_lo, w_hi, gather_bits(c & 0x00300C03u))) {   // main.cpp:139-142
-                live = 0;
-                h.steps = iter + 1;
-                h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
-                h.payload = h.index;
+        if (r_any) {                                     // ... unless the region holds voxels:
+            const uint32_t brick = c & 0xFFCFF3FCu;
+            watch = brick;                               // then quiet until it leaves this 4^3 brick ...
+            wmask = 0xFFCFF3FCu;
+            if (test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {      // ... unless the brick holds voxels:
+                watch = 0xFFFFFFFFu;                     // then every step is looked at
+                if (brick != last_brick) {
+                    uint64_t bits = g.occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
+                    w_lo = (uint32_t)bits;
+                    w_hi = (uint32_t)(bits >> 32);
+                    last_brick = brick;
+                }
+                if (test_word(w_lo, w_hi, gather_bits(c & 0x00300C03u))) {   // main.cpp:139-142
+                    live = 0;
+                    h.steps = iter + 1;
+                    h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
+                    h.payload = h.index;
+                }
             }
         }
         if (!live) break;
