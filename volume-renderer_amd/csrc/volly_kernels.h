@@ -446,14 +446,28 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
     return h;
 }
 
-// trace_dense_regular<true> with the quiet steps in assembly (VK_ASM_QUIET).  Measured: in 52 % of
-// the wave-steps of the headline workload no lane changes its 16^3 region or sits in a region
-// with voxels (profiles/r01_ab/count_quiet_steps.log); such a step needs no per-lane test at all.
-// The assembly loop runs those steps back to back -- 29 vector and 5 scalar instructions each,
-// against 35 and ~20 in the compiled loop -- and hands the first step that needs attention (or
-// reaches the iteration cap), with its sample point, cell and packed cell already computed, to
-// the same per-lane code as before.  `watch` is the lane's region key while that region is known
-// to be empty, else 0xFFFFFFFF, which no key equals.
+// trace_dense_regular<true> with the common steps in assembly (VK_ASM_QUIET).
+//
+// A lane is *quiet* while (cell & wmask) == watch: watch / wmask name its 16^3 region while that
+// region is known to be empty, its 4^3 brick while the region holds voxels but the brick does
+// not, and watch is 0xFFFFFFFF (which no key equals) inside a brick with voxels.  Measured: in
+// 57 % of the wave-steps of the headline workload every live lane is quiet
+// (profiles/r01_ab/count_quiet_steps.log, count_asm_loop_exits.log); such a step needs no per-lane
+// test at all, and most of the others are a lane entering another region or another empty brick.
+// The assembly loop runs
+//   * quiet steps back to back: 29 vector and 5 scalar instructions each (35 and ~20 compiled);
+//   * region changes inside the grid (bounds test, load of the region word) and moves to
+//     another empty brick for the lanes that need them, under an exec mask of its own,
+// and leaves -- state consistent, the step not yet taken -- when a lane leaves the grid, enters a
+// brick that holds voxels, or the iteration cap is reached; the per-lane C++ code below then
+// handles that one step for every lane and re-enters.
+//
+// Registers: v47-v55 are the loop's own temporaries (clobbers).  Its three exec masks are
+// operands, so that the compiler places them: fixed high scalar registers cost the kernel its
+// eighth wavefront per SIMD (800 scalar registers per SIMD: 8 waves need <= 96 each).  The iteration
+// number lives in m0: the compiler will not keep a loop-carried value of a divergent loop in a
+// scalar register ("illegal VGPR to SGPR copy"), and nothing else in these kernels uses m0 (no
+// LDS, no indexed registers, no messages; tests/test_m0_is_ours.py reads the assembly).
 __device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
     Hit h;
@@ -463,84 +477,133 @@ __device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const 
     h.payload = VOLLY_MISS_INDEX;
     if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
     uint32_t last_brick = 0xFFFFFFFFu, w_lo = 0, w_hi = 0;
-    uint32_t last_region = 0xFFFFFFFFu, r_lo = 0, r_hi = 0, r_any = 0;
+    uint32_t last_region = 0xFFFFFFFFu;
+    uint64_t rw = 0;                                     // the region word: which of the region's 64 bricks hold voxels
     uint32_t watch = 0xFFFFFFFFu, wmask = 0xFF0FC3F0u;
     uint32_t live = 1;
-    // The iteration number is the same in every lane still in the loop.  The compiler will not
-    // keep a loop-carried value of a divergent loop in a scalar register ("illegal VGPR to SGPR
-    // copy"), so it lives in m0, which nothing else in these kernels uses (no LDS, no indexed
-    // registers, no messages), and is read into a scalar register where C++ needs it.
     const uint32_t cap = g.cap;
+    const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz, nrx = (uint32_t)g.nrx, nry = (uint32_t)g.nry;
+    const uint64_t *occ2 = g.occ2;
     asm volatile("s_mov_b32 m0, 0");
     for (;;) {
-        float px, py, pz, t0, t1, t2;
-        int x, y, z;
         uint32_t c;
+        uint64_t mask_a, mask_b, mask_c;                  // exec masks of the loop's own
         asm volatile(
-            "1:\n\t"
-            "v_add_f32 %[px], %[cx], %[ex]\n\t"
-            "v_add_f32 %[py], %[cy], %[ey]\n\t"
-            "v_add_f32 %[pz], %[cz], %[ez]\n\t"
-            "v_cvt_i32_f32 %[x], %[px]\n\t"
-            "v_cvt_i32_f32 %[y], %[py]\n\t"
-            "v_cvt_i32_f32 %[z], %[pz]\n\t"
-            "v_lshl_or_b32 %[c], %[y], 10, %[x]\n\t"
-            "v_lshl_or_b32 %[c], %[z], 20, %[c]\n\t"
-            "v_and_b32 %[t0], %[wmask], %[c]\n\t"
-            "v_cmp_ne_u32 vcc, %[t0], %[watch]\n\t"
-            "s_cbranch_vccnz 2f\n\t"
+            "1:\n\t"                                      // ---- one step: sample point, cell, key
+            "v_add_f32 v47, %[cx], %[ex]\n\t"
+            "v_add_f32 v48, %[cy], %[ey]\n\t"
+            "v_add_f32 v49, %[cz], %[ez]\n\t"
+            "v_cvt_i32_f32 v50, v47\n\t"
+            "v_cvt_i32_f32 v51, v48\n\t"
+            "v_cvt_i32_f32 v52, v49\n\t"
+            "v_lshl_or_b32 %[c], v51, 10, v50\n\t"
+            "v_lshl_or_b32 %[c], v52, 20, %[c]\n\t"
+            "v_and_b32 v53, %[wmask], %[c]\n\t"
+            "v_cmp_ne_u32 vcc, v53, %[watch]\n\t"
+            "s_cbranch_vccnz 3f\n\t"
             "s_cmp_ge_u32 m0, %[cap]\n\t"
-            "s_cbranch_scc1 2f\n\t"
-            "v_floor_f32 %[t0], %[px]\n\t"
-            "v_floor_f32 %[t1], %[py]\n\t"
-            "v_floor_f32 %[t2], %[pz]\n\t"
-            "v_add_f32 %[t0], %[t0], %[hx]\n\t"
-            "v_add_f32 %[t1], %[t1], %[hy]\n\t"
-            "v_add_f32 %[t2], %[t2], %[hz]\n\t"
-            "v_sub_f32 %[t0], %[t0], %[cx]\n\t"
-            "v_sub_f32 %[t1], %[t1], %[cy]\n\t"
-            "v_sub_f32 %[t2], %[t2], %[cz]\n\t"
-            "v_mul_f32 %[t0], %[t0], %[ix]\n\t"
-            "v_mul_f32 %[t1], %[t1], %[iy]\n\t"
-            "v_mul_f32 %[t2], %[t2], %[iz]\n\t"
-            "v_min3_f32 %[t0], %[t0], %[t1], %[t2]\n\t"
-            "v_mul_f32 %[t1], %[t0], %[dx]\n\t"
-            "v_mul_f32 %[t2], %[t0], %[dy]\n\t"
-            "v_mul_f32 %[t0], %[t0], %[dz]\n\t"
-            "v_add_f32 %[cx], %[t1], %[cx]\n\t"
-            "v_add_f32 %[cy], %[t2], %[cy]\n\t"
-            "v_add_f32 %[cz], %[t0], %[cz]\n\t"
+            "s_cbranch_scc1 9f\n"
+            "2:\n\t"                                      // ---- advance_unit (main.cpp:149-153), every live lane
+            "v_floor_f32 v53, v47\n\t"
+            "v_floor_f32 v54, v48\n\t"
+            "v_floor_f32 v55, v49\n\t"
+            "v_add_f32 v53, v53, %[hx]\n\t"
+            "v_add_f32 v54, v54, %[hy]\n\t"
+            "v_add_f32 v55, v55, %[hz]\n\t"
+            "v_sub_f32 v53, v53, %[cx]\n\t"
+            "v_sub_f32 v54, v54, %[cy]\n\t"
+            "v_sub_f32 v55, v55, %[cz]\n\t"
+            "v_mul_f32 v53, v53, %[ix]\n\t"
+            "v_mul_f32 v54, v54, %[iy]\n\t"
+            "v_mul_f32 v55, v55, %[iz]\n\t"
+            "v_min3_f32 v53, v53, v54, v55\n\t"
+            "v_mul_f32 v54, v53, %[dx]\n\t"
+            "v_mul_f32 v55, v53, %[dy]\n\t"
+            "v_mul_f32 v53, v53, %[dz]\n\t"
+            "v_add_f32 %[cx], v54, %[cx]\n\t"
+            "v_add_f32 %[cy], v55, %[cy]\n\t"
+            "v_add_f32 %[cz], v53, %[cz]\n\t"
             "s_add_u32 m0, m0, 1\n\t"
             "s_branch 1b\n"
-            "2:"
-            : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz),
-              [px] "=&v"(px), [py] "=&v"(py), [pz] "=&v"(pz), [x] "=&v"(x), [y] "=&v"(y), [z] "=&v"(z), [c] "=&v"(c),
-              [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+            "3:\n\t"                                      // ---- vcc = the lanes that are not quiet
+            "s_cmp_ge_u32 m0, %[cap]\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            "s_mov_b64 %[sa], exec\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "v_and_b32 v53, 0xff0fc3f0, %[c]\n\t"         // region key
+            "v_cmp_ne_u32 vcc, v53, %[lastr]\n\t"
+            "s_and_saveexec_b64 %[sb], vcc\n\t"        // lanes in a new region
+            "s_cbranch_execz 5f\n\t"
+            "v_cmp_gt_u32 vcc, %[sx], v50\n\t"
+            "v_cmp_gt_u32 %[sc], %[sy], v51\n\t"
+            "s_and_b64 vcc, vcc, %[sc]\n\t"
+            "v_cmp_gt_u32 %[sc], %[sz], v52\n\t"
+            "s_and_b64 vcc, vcc, %[sc]\n\t"
+            "s_xor_b64 %[sc], vcc, exec\n\t"           // a lane left the grid: the C++ code ends it
+            "s_cbranch_scc1 8f\n\t"
+            "v_lshrrev_b32 v54, 4, v52\n\t"               // region index x>>4 + nrx * (y>>4 + nry * (z>>4))
+            "v_lshrrev_b32 v55, 4, v51\n\t"
+            "v_mad_u32_u24 v54, v54, %[nry], v55\n\t"
+            "v_lshrrev_b32 v55, 4, v50\n\t"
+            "v_mad_u32_u24 v54, v54, %[nrx], v55\n\t"
+            "v_lshlrev_b32 v54, 3, v54\n\t"
+            "global_load_dwordx2 %[rw], v54, %[occ2]\n\t"
+            "v_mov_b32 %[lastr], v53\n\t"
+            "s_waitcnt vmcnt(0)\n"
+            "5:\n\t"
+            "s_mov_b64 exec, %[sb]\n\t"                // the lanes that are not quiet again
+            "v_cmp_eq_u64 vcc, 0, %[rw]\n\t"              // empty region: quiet until the lane leaves it
+            "v_mov_b32 v54, 0xff0fc3f0\n\t"
+            "v_cndmask_b32 %[watch], %[watch], v53, vcc\n\t"
+            "v_cndmask_b32 %[wmask], %[wmask], v54, vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"             // lanes in a region with voxels: look at the brick's bit
+            "s_cbranch_execz 7f\n\t"
+            "v_lshrrev_b32 v54, 2, %[c]\n\t"
+            "v_and_b32 v54, 0x300c03, v54\n\t"
+            "v_mul_u32_u24 v54, 0x40404, v54\n\t"
+            "v_bfe_u32 v54, v54, 18, 6\n\t"
+            "v_lshrrev_b64 v[54:55], v54, %[rw]\n\t"
+            "v_and_b32 v54, 1, v54\n\t"
+            "v_cmp_eq_u32 vcc, 1, v54\n\t"
+            "s_cbranch_vccnz 8f\n\t"                      // a brick with voxels: the C++ code tests the voxel
+            "v_and_b32 %[watch], 0xffcff3fc, %[c]\n\t"    // an empty brick: quiet until the lane leaves it
+            "v_mov_b32 %[wmask], 0xffcff3fc\n"
+            "7:\n\t"
+            "s_mov_b64 exec, %[sa]\n\t"
+            "s_branch 2b\n"
+            "8:\n\t"
+            "s_mov_b64 exec, %[sa]\n"
+            "9:"
+            : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [c] "=&v"(c),
+              [lastr] "+v"(last_region), [rw] "+v"(rw), [watch] "+v"(watch), [wmask] "+v"(wmask),
+              [sa] "=&s"(mask_a), [sb] "=&s"(mask_b), [sc] "=&s"(mask_c)
             : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
               [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-              [watch] "v"(watch), [wmask] "v"(wmask), [cap] "s"(cap)
-            : "vcc", "scc");
+              [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [nrx] "s"(nrx), [nry] "s"(nry), [occ2] "s"(occ2)
+            : "vcc", "scc", "memory", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
         uint32_t iter;
         asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
         if (iter >= cap) { h.steps = iter; break; }      // uniform
+        // the step the loop stopped at, for every live lane (everything it may already have done
+        // for some of them -- region word, watch -- is found done again here)
+        const float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
+        const int x = (int)px, y = (int)py, z = (int)pz;
         const uint32_t region = c & 0xFF0FC3F0u;
         if (region != last_region) {
-            bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
+            bool inside = ((uint32_t)x < sx) & ((uint32_t)y < sy) & ((uint32_t)z < sz);
             if (inside) {
-                uint64_t bits = g.occ2[cell_index24(x >> 4, y >> 4, z >> 4, g.nrx, g.nry)];
-                r_lo = (uint32_t)bits;
-                r_hi = (uint32_t)(bits >> 32);
-                r_any = (r_lo | r_hi) != 0u;
+                rw = occ2[cell_index24(x >> 4, y >> 4, z >> 4, g.nrx, g.nry)];
                 last_region = region;
                 watch = region;                          // quiet until the lane leaves this region ...
                 wmask = 0xFF0FC3F0u;
             } else {                                     // left the grid: main.cpp:126-135
-                r_any = 0;
+                rw = 0;
                 live = 0;
                 h.steps = iter;
             }
         }
-        if (r_any) {                                     // ... unless the region holds voxels:
+        if (rw != 0) {                                   // ... unless the region holds voxels:
+            const uint32_t r_lo = (uint32_t)rw, r_hi = (uint32_t)(rw >> 32);
             const uint32_t brick = c & 0xFFCFF3FCu;
             watch = brick;                               // then quiet until it leaves this 4^3 brick ...
             wmask = 0xFFCFF3FCu;
