@@ -40,6 +40,7 @@
 //   VK_INDEX24=0      32-bit multiplies for the brick / region index in the regular loop
 //   VK_PACK_ASM=0     let the compiler choose the instructions that pack a cell
 //   VK_ASM_QUIET=0    the compiled region loop only (no assembly loop for the quiet steps)
+//   VK_ASM_EXTRA=0    the compiled loop for the serial adds past a checkpoint
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
 //   VK_TILES_PER_WAVE=K  a wavefront renders K tiles one after the other and asks for the next
 //                     tile's checkpoint early (measured 15-35 % slower for K = 2, 4, 8)
@@ -82,6 +83,9 @@
 #endif
 #ifndef VK_ASM_QUIET
 #define VK_ASM_QUIET 1
+#endif
+#ifndef VK_ASM_EXTRA
+#define VK_ASM_EXTRA 1
 #endif
 #ifndef VK_PACK_ASM
 #define VK_PACK_ASM 1
@@ -905,11 +909,50 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
 {
     PixelOut o;
     float hx = k.v[0], hy = k.v[1], hz = k.v[2], lx = k.v[3], ly = k.v[4], lz = k.v[5];
+#if VK_ASM_EXTRA && VK_WAVE_BLOCK && !VK_LINEAR_TILE && VK_CKPT_STRIDE == 8
+    // main.cpp:282-283: lane l of an 8-pixel row segment is l & 7 serial adds past its checkpoint.
+    // Which lanes still add in round i is known at compile time (every eighth lane drops out per
+    // round), so the rounds run under constant exec masks: 7 x (2 scalar + 6 vector)
+    // instructions, where the compiled loop over a per-lane trip count spends 7 x (10 + 8).
+    {
+        const float ah = fd.xdiff_hi[0], bh = fd.xdiff_hi[1], ch = fd.xdiff_hi[2];
+        const float al = fd.xdiff_lo[0], bl = fd.xdiff_lo[1], cl = fd.xdiff_lo[2];
+        (void)xrel;
+#define VK_EXTRA_ROUND(MASK)                                                                     \
+            "s_and_b32 exec_lo, %[save0], " MASK "\n\t"                                          \
+            "s_and_b32 exec_hi, %[save1], " MASK "\n\t"                                          \
+            "v_add_f32 %[hx], %[hx], %[ah]\n\t"                                                  \
+            "v_add_f32 %[hy], %[hy], %[bh]\n\t"                                                  \
+            "v_add_f32 %[hz], %[hz], %[ch]\n\t"                                                  \
+            "v_add_f32 %[lx], %[lx], %[al]\n\t"                                                  \
+            "v_add_f32 %[ly], %[ly], %[bl]\n\t"                                                  \
+            "v_add_f32 %[lz], %[lz], %[cl]\n\t"
+        uint32_t save0, save1;
+        asm volatile(
+            "s_mov_b32 %[save0], exec_lo\n\t"
+            "s_mov_b32 %[save1], exec_hi\n\t"
+            VK_EXTRA_ROUND("0xfefefefe")
+            VK_EXTRA_ROUND("0xfcfcfcfc")
+            VK_EXTRA_ROUND("0xf8f8f8f8")
+            VK_EXTRA_ROUND("0xf0f0f0f0")
+            VK_EXTRA_ROUND("0xe0e0e0e0")
+            VK_EXTRA_ROUND("0xc0c0c0c0")
+            VK_EXTRA_ROUND("0x80808080")
+            "s_mov_b32 exec_lo, %[save0]\n\t"
+            "s_mov_b32 exec_hi, %[save1]"
+            : [hx] "+v"(hx), [hy] "+v"(hy), [hz] "+v"(hz), [lx] "+v"(lx), [ly] "+v"(ly), [lz] "+v"(lz),
+              [save0] "=&s"(save0), [save1] "=&s"(save1)
+            : [ah] "s"(ah), [bh] "s"(bh), [ch] "s"(ch), [al] "s"(al), [bl] "s"(bl), [cl] "s"(cl)
+            : "scc");
+#undef VK_EXTRA_ROUND
+    }
+#else
     const int extra = xrel % kCkpt;
     for (int i = 0; i < extra; ++i) {                     // main.cpp:282-283
         hx = hx + fd.xdiff_hi[0]; hy = hy + fd.xdiff_hi[1]; hz = hz + fd.xdiff_hi[2];
         lx = lx + fd.xdiff_lo[0]; ly = ly + fd.xdiff_lo[1]; lz = lz + fd.xdiff_lo[2];
     }
+#endif
     const float hw = normalize_w0(hx, hy, hz);            // main.cpp:260
     const Ray ray_hi = make_ray(hx, hy, hz);
     if constexpr (!SVO && RAYTRACE) {
