@@ -41,6 +41,7 @@
 //   VK_PACK_ASM=0     let the compiler choose the instructions that pack a cell
 //   VK_ASM_QUIET=0    the compiled region loop only (no assembly loop for the quiet steps)
 //   VK_ASM_EXTRA=0    the compiled loop for the serial adds past a checkpoint
+//   VK_ASM_BRICKS=0   the compiled loop for grids without the region level
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
 //   VK_TILES_PER_WAVE=K  a wavefront renders K tiles one after the other and asks for the next
 //                     tile's checkpoint early (measured 15-35 % slower for K = 2, 4, 8)
@@ -86,6 +87,9 @@
 #endif
 #ifndef VK_ASM_EXTRA
 #define VK_ASM_EXTRA 1
+#endif
+#ifndef VK_ASM_BRICKS
+#define VK_ASM_BRICKS 1
 #endif
 #ifndef VK_PACK_ASM
 #define VK_PACK_ASM 1
@@ -634,6 +638,140 @@ __device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const 
     return h;
 }
 
+// trace_dense_regular<false> (bricks only: grids whose 16^3 regions nearly all hold voxels, e.g.
+// the noise volume) with the whole step in assembly (VK_ASM_BRICKS).  In such a grid some lane of
+// the wavefront enters a new 4^3 brick on almost every step, so there are no quiet steps to run
+// ahead with; what the assembly saves is the exec-mask bookkeeping of the compiled per-lane
+// tests: a step is the sample point and cell (11 vector instructions), for the lanes in a new
+// brick the bounds test, brick index and load of its word (9 + the load), for the lanes whose
+// brick holds voxels the test of the cell's bit (9), and the advance (19).  It leaves -- state
+// consistent, the step not yet taken -- when a lane leaves the grid or samples a voxel (the
+// per-lane C++ code below ends that lane) or at the iteration cap.  Same registers and m0
+// convention as trace_dense_regular_asm.
+__device__ __forceinline__ Hit trace_dense_bricks_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
+    uint32_t last_brick = 0xFFFFFFFFu;
+    uint64_t w = 0;                                      // the brick word: which of the brick's 64 cells hold a voxel
+    uint32_t live = 1;
+    const uint32_t cap = g.cap;
+    const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz, nbx = (uint32_t)g.nbx, nby = (uint32_t)g.nby;
+    const uint64_t *occ = g.occ;
+    asm volatile("s_mov_b32 m0, 0");
+    for (;;) {
+        uint32_t c;
+        uint64_t mask_a, mask_b;
+        asm volatile(
+            "1:\n\t"                                      // ---- sample point, cell, brick key
+            "v_add_f32 v47, %[cx], %[ex]\n\t"
+            "v_add_f32 v48, %[cy], %[ey]\n\t"
+            "v_add_f32 v49, %[cz], %[ez]\n\t"
+            "v_cvt_i32_f32 v50, v47\n\t"
+            "v_cvt_i32_f32 v51, v48\n\t"
+            "v_cvt_i32_f32 v52, v49\n\t"
+            "v_lshl_or_b32 %[c], v51, 10, v50\n\t"
+            "v_lshl_or_b32 %[c], v52, 20, %[c]\n\t"
+            "s_cmp_ge_u32 m0, %[cap]\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            "v_and_b32 v53, 0xffcff3fc, %[c]\n\t"
+            "v_cmp_ne_u32 vcc, v53, %[lastb]\n\t"
+            "s_cbranch_vccz 4f\n\t"
+            "s_and_saveexec_b64 %[sa], vcc\n\t"           // ---- lanes in a new brick
+            "v_cmp_gt_u32 vcc, %[sx], v50\n\t"
+            "v_cmp_gt_u32 %[sb], %[sy], v51\n\t"
+            "s_and_b64 vcc, vcc, %[sb]\n\t"
+            "v_cmp_gt_u32 %[sb], %[sz], v52\n\t"
+            "s_and_b64 vcc, vcc, %[sb]\n\t"
+            "s_xor_b64 %[sb], vcc, exec\n\t"              // a lane left the grid: the C++ code ends it
+            "s_cbranch_scc1 8f\n\t"
+            "v_lshrrev_b32 v54, 2, v52\n\t"               // brick index x>>2 + nbx * (y>>2 + nby * (z>>2))
+            "v_lshrrev_b32 v55, 2, v51\n\t"
+            "v_mad_u32_u24 v54, v54, %[nby], v55\n\t"
+            "v_lshrrev_b32 v55, 2, v50\n\t"
+            "v_mad_u32_u24 v54, v54, %[nbx], v55\n\t"
+            "v_lshlrev_b32 v54, 3, v54\n\t"
+            "global_load_dwordx2 %[w], v54, %[occ]\n\t"
+            "v_mov_b32 %[lastb], v53\n\t"
+            "s_waitcnt vmcnt(0)\n\t"
+            "s_mov_b64 exec, %[sa]\n"
+            "4:\n\t"                                      // ---- lanes whose brick holds voxels: the cell's bit
+            "v_cmp_ne_u64 vcc, 0, %[w]\n\t"
+            "s_cbranch_vccz 6f\n\t"
+            "s_and_saveexec_b64 %[sa], vcc\n\t"
+            "v_and_b32 v54, 0x300c03, %[c]\n\t"
+            "v_mul_u32_u24 v54, 0x40404, v54\n\t"
+            "v_bfe_u32 v54, v54, 18, 6\n\t"
+            "v_lshrrev_b64 v[54:55], v54, %[w]\n\t"
+            "v_and_b32 v54, 1, v54\n\t"
+            "v_cmp_eq_u32 vcc, 1, v54\n\t"
+            "s_cbranch_vccnz 8f\n\t"                      // a voxel: the C++ code records the hit
+            "s_mov_b64 exec, %[sa]\n"
+            "6:\n\t"                                      // ---- advance_unit (main.cpp:149-153)
+            "v_floor_f32 v53, v47\n\t"
+            "v_floor_f32 v54, v48\n\t"
+            "v_floor_f32 v55, v49\n\t"
+            "v_add_f32 v53, v53, %[hx]\n\t"
+            "v_add_f32 v54, v54, %[hy]\n\t"
+            "v_add_f32 v55, v55, %[hz]\n\t"
+            "v_sub_f32 v53, v53, %[cx]\n\t"
+            "v_sub_f32 v54, v54, %[cy]\n\t"
+            "v_sub_f32 v55, v55, %[cz]\n\t"
+            "v_mul_f32 v53, v53, %[ix]\n\t"
+            "v_mul_f32 v54, v54, %[iy]\n\t"
+            "v_mul_f32 v55, v55, %[iz]\n\t"
+            "v_min3_f32 v53, v53, v54, v55\n\t"
+            "v_mul_f32 v54, v53, %[dx]\n\t"
+            "v_mul_f32 v55, v53, %[dy]\n\t"
+            "v_mul_f32 v53, v53, %[dz]\n\t"
+            "v_add_f32 %[cx], v54, %[cx]\n\t"
+            "v_add_f32 %[cy], v55, %[cy]\n\t"
+            "v_add_f32 %[cz], v53, %[cz]\n\t"
+            "s_add_u32 m0, m0, 1\n\t"
+            "s_branch 1b\n"
+            "8:\n\t"
+            "s_mov_b64 exec, %[sa]\n"
+            "9:"
+            : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [c] "=&v"(c),
+              [lastb] "+v"(last_brick), [w] "+v"(w), [sa] "=&s"(mask_a), [sb] "=&s"(mask_b)
+            : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
+              [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
+              [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [nbx] "s"(nbx), [nby] "s"(nby), [occ] "s"(occ)
+            : "vcc", "scc", "memory", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        uint32_t iter;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
+        if (iter >= cap) { h.steps = iter; break; }      // uniform
+        // the step the loop stopped at, for every live lane
+        const float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
+        const int x = (int)px, y = (int)py, z = (int)pz;
+        const uint32_t brick = c & 0xFFCFF3FCu;
+        if (brick != last_brick) {
+            bool inside = ((uint32_t)x < sx) & ((uint32_t)y < sy) & ((uint32_t)z < sz);
+            if (inside) {
+                w = occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
+                last_brick = brick;
+            } else {                                     // left the grid: main.cpp:126-135
+                live = 0;
+                h.steps = iter;
+            }
+        }
+        if (live && test_word((uint32_t)w, (uint32_t)(w >> 32), gather_bits(c & 0x00300C03u))) {   // main.cpp:139-142
+            live = 0;
+            h.steps = iter + 1;
+            h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
+            h.payload = h.index;
+        }
+        if (!live) break;
+        advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
+        asm volatile("s_add_u32 m0, m0, 1" : : : "scc");
+    }
+    return h;
+}
+
 __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
 #if VK_FAST_DDA && !VK_AOS_SAMPLE
@@ -645,7 +783,11 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
 #else
         if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regular<true>(g, r, ox, oy, oz);
 #endif
+#if VK_ASM_BRICKS
+        return trace_dense_bricks_asm(g, r, ox, oy, oz);
+#else
         return trace_dense_regular<false>(g, r, ox, oy, oz);
+#endif
     }
 #endif
     return trace_dense_checked<false>(g, r, ox, oy, oz);
