@@ -65,7 +65,7 @@ tools/valu_rate: tools/valu_rate.hip
 VARDIR := $(LIBDIR)/variants
 variants:
 	@mkdir -p $(VARDIR)
-	for v in checked:-DVK_FAST_DDA=0 aos:-DVK_AOS_SAMPLE=1 'linear:-DVK_LINEAR_TILE=1 -DVK_WAVE_BLOCK=0' xcd:-DVK_XCD_REMAP=1 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 'rootwalk_nolds:-DVK_SVO_TABLE=0 -DVK_LDS_TOP=0' block256:-DVK_WAVE_BLOCK=0 waves4:-DVK_WAVE_BLOCK=4 longdiv:-DVK_SHORT_DIV=0 index32:-DVK_INDEX24=0 ckpt4:-DVK_CKPT_STRIDE=4 packc:-DVK_PACK_ASM=0 noasm:-DVK_ASM_QUIET=0 noasmextra:-DVK_ASM_EXTRA=0 noasmbricks:-DVK_ASM_BRICKS=0 tiles2:-DVK_TILES_PER_WAVE=2 tiles4:-DVK_TILES_PER_WAVE=4 w6:-DVK_PROBE_WAVES=6 w4:-DVK_PROBE_WAVES=4 slp:-fslp-vectorize; do \
+	for v in checked:-DVK_FAST_DDA=0 aos:-DVK_AOS_SAMPLE=1 'linear:-DVK_LINEAR_TILE=1 -DVK_WAVE_BLOCK=0' xcd:-DVK_XCD_REMAP=1 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 'rootwalk_nolds:-DVK_SVO_TABLE=0 -DVK_LDS_TOP=0' block256:-DVK_WAVE_BLOCK=0 waves4:-DVK_WAVE_BLOCK=4 longdiv:-DVK_SHORT_DIV=0 index32:-DVK_INDEX24=0 ckpt4:-DVK_CKPT_STRIDE=4 packc:-DVK_PACK_ASM=0 noasm:-DVK_ASM_QUIET=0 noasmextra:-DVK_ASM_EXTRA=0 noasmbricks:-DVK_ASM_BRICKS=0 nobfi:-DVK_SIGN_BFI=0 tiles2:-DVK_TILES_PER_WAVE=2 tiles4:-DVK_TILES_PER_WAVE=4 w6:-DVK_PROBE_WAVES=6 w4:-DVK_PROBE_WAVES=4 slp:-fslp-vectorize; do \
 	  n=$${v%%:*}; f="$${v#*:}"; \
 	  $(HIPCC) $(GPUFLAGS) $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(GPU_SRC) || exit 1; \
 	done

@@ -42,6 +42,7 @@
 //   VK_ASM_QUIET=0    the compiled region loop only (no assembly loop for the quiet steps)
 //   VK_ASM_EXTRA=0    the compiled loop for the serial adds past a checkpoint
 //   VK_ASM_BRICKS=0   the compiled loop for grids without the region level
+//   VK_SIGN_BFI=0     sign(d) * eps by compares, conversion and multiply also for regular wavefronts
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
 //   VK_TILES_PER_WAVE=K  a wavefront renders K tiles one after the other and asks for the next
 //                     tile's checkpoint early (measured 15-35 % slower for K = 2, 4, 8)
@@ -90,6 +91,9 @@
 #endif
 #ifndef VK_ASM_BRICKS
 #define VK_ASM_BRICKS 1
+#endif
+#ifndef VK_SIGN_BFI
+#define VK_SIGN_BFI 1
 #endif
 #ifndef VK_PACK_ASM
 #define VK_PACK_ASM 1
@@ -223,6 +227,12 @@ __device__ __forceinline__ Ray make_ray(float dx, float dy, float dz)
     r.hx = (dx < 0.0f) ? 0.0f : 1.0f;
     r.hy = (dy < 0.0f) ? 0.0f : 1.0f;
     r.hz = (dz < 0.0f) ? 0.0f : 1.0f;
+#if VK_SIGN_BFI
+    if (__all(r.regular)) {                               // no zero, no NaN: sign(d) * eps is eps with d's sign bit (one v_bfi_b32 each)
+        r.ex = __builtin_copysignf(eps, dx); r.ey = __builtin_copysignf(eps, dy); r.ez = __builtin_copysignf(eps, dz);
+        return r;
+    }
+#endif
     float sx = (float)((0.0f < dx) - (dx < 0.0f));
     float sy = (float)((0.0f < dy) - (dy < 0.0f));
     float sz = (float)((0.0f < dz) - (dz < 0.0f));
@@ -874,7 +884,7 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
 // glm::normalize(vec4(x,y,z,0)): v * (1/sqrt((xx+yy)+(zz+ww))); returns the w component 0 * inversesqrt
 __device__ __forceinline__ float normalize_w0(float &x, float &y, float &z)
 {
-    float d = (x * x + y * y) + (z * z + 0.0f);
+    float d = (x * x + y * y) + z * z;                   // (z*z + w*w) with w = 0: z*z is never -0, so adding +0 changes no bit
     float inv;
     if (VK_SHORT_DIV && in_fast_range(d)) inv = rcp_in_range(sqrt_in_range(d));   // sqrt of [2^-100, 2^100] lies in [2^-50, 2^50]
     else inv = 1.0f / sqrtf(d);
