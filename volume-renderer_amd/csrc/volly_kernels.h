@@ -993,6 +993,7 @@ __device__ __forceinline__ void checkpoint_chain(const volly_frame_desc &fd, int
     const int groups = (tile_w + kCkpt - 1) / kCkpt;
     float *o = ckpt + ((size_t)f * (size_t)groups * 6 + (size_t)comp) * (size_t)tile_h + (size_t)yrel;
     const size_t stride = (size_t)tile_h * 6;
+    #pragma unroll 4
     for (int g = 0; g < groups; ++g) {
         o[(size_t)g * stride] = v;
         #pragma unroll
