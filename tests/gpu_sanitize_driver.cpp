@@ -1,6 +1,6 @@
 // gpu_sanitize_driver.cpp -- walks the C-ABI of libvolly_gpu.so (include/volly_gpu.h) with the
 // HOST side of the library compiled under AddressSanitizer (device code is not instrumented:
-// GPU sanitizers are not available on this pool).  Built and run by hand, see DESIGN.md section 6:
+// GPU sanitizers are not available on this pool).  Built and run by hand, see DESIGN.md section 3:
 //
 //   make sanitize-gpu            # builds build/san/{lib/*.so, gpu_sanitize_driver}
 //   build/san/gpu_sanitize_driver assets        # on a box with an MI355X
