@@ -105,7 +105,7 @@
 #define VK_CKPT_STRIDE 8
 #endif
 
-static_assert(!(VK_LINEAR_TILE && VK_WAVE_BLOCK), "the 32x2 wavefront tile needs the 32x8 workgroup (VK_WAVE_BLOCK=0)");
+static_assert(!((VK_LINEAR_TILE != 0) && (VK_WAVE_BLOCK != 0)), "the 32x2 wavefront tile needs the 32x8 workgroup (VK_WAVE_BLOCK=0)");
 
 namespace vk {
 
