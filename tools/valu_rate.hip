@@ -44,6 +44,16 @@ __device__ __forceinline__ float sink(int a, int b, int c, int d, int e, int f, 
 #define RCPF(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(x))
 #define PKADD(x) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p##x) : "v"(pk))
 
+#define U64x4 unsigned long long b0 = (unsigned long long)seed * 0x9E3779B97F4A7C15ull + threadIdx.x, b1 = b0 + 1, b2 = b0 + 2, b3 = b0 + 3; uint32_t k = threadIdx.x & 31; float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0
+#define LSHR64(x) asm volatile("v_lshrrev_b64 %0, %1, %0" : "+v"(x) : "v"(k))
+#define CMP64(x) asm volatile("v_cmp_eq_u64 vcc, 0, %0" : : "v"(x) : "vcc")
+#define ALL4(op) op(b0); op(b1); op(b2); op(b3); op(b0); op(b1); op(b2); op(b3)
+#define MADU24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(x) : "v"(k))
+#define LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(x) : "v"(k))
+KERNEL(k_lshrrev_b64, U64x4, ALL4(LSHR64); a0 += (float)(b0 ^ b1 ^ b2 ^ b3))
+KERNEL(k_cmp_eq_u64, U64x4, ALL4(CMP64); a0 += (float)(b0 ^ b1 ^ b2 ^ b3))
+KERNEL(k_mad_u32_u24, U8, ALL(MADU24))
+KERNEL(k_lshl_add_u32, U8, ALL(LSHLADD))
 KERNEL(k_add_f32, F8, ALL(ADDF))
 KERNEL(k_mul_f32, F8, ALL(MULF))
 KERNEL(k_fma_f32, F8, ALL(FMAF))
@@ -130,6 +140,7 @@ int main()
     RUN(k_add_f32); RUN(k_mul_f32); RUN(k_fma_f32); RUN(k_floor_f32); RUN(k_min3_f32); RUN(k_cvt_i32_f32); RUN(k_rcp_f32); RUN(k_cmp_f32);
     RUN(k_and_b32); RUN(k_lshl_b32); RUN(k_or3_b32); RUN(k_lshl_or_b32); RUN(k_add_u32); RUN(k_cmp_u32); RUN(k_cndmask); RUN(k_mov_b32);
     RUN(k_mul_u24); RUN(k_bfe_u32); RUN(k_pk_add_f32);
+    RUN(k_lshrrev_b64); RUN(k_cmp_eq_u64); RUN(k_mad_u32_u24); RUN(k_lshl_add_u32);
     RUN(k_add_f32_low32); RUN(k_add_f32_low16); RUN(k_add_f32_even); RUN(k_add_f32_1of4rows);
     RUN(k_floor_f32_low32); RUN(k_floor_f32_low16); RUN(k_floor_f32_even); RUN(k_cvt_low32); RUN(k_lshl_or_low32);
     return 0;
