@@ -155,6 +155,22 @@ void  volly_gpu_host_free(void *p);
 int volume_gpu_render_device(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames,
                              const volly_outputs *outs, void *hip_stream);
 
+/* volume_gpu_render_device for callers that cannot allocate.  It has NO counterpart in the
+ * reference (which never allocates per frame: main.cpp:197-291 works in the locked texture); it is
+ * for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same arguments, same results bit for bit; it calls no
+ * hipMalloc / hipFree / allocating library routine and takes its scratch (frame descriptors and
+ * direction checkpoints) from a 32 MiB + 4 KiB array that lives in the library's device image --
+ * each GPU the library runs on holds its copy until the process ends.
+ * Limit: one sub-rectangle's checkpoints, 6 * ceil(tile_w / 8) * tile_h floats, must fit 32 MiB
+ * (up to ~11 Mpixel: a 3840x2160 frame fits, a 7680x4320 frame needs row bands of <= 1456 rows);
+ * larger ones are rejected with VOLLY_E_ARG.  Any number of frames: they are rendered in launches
+ * of as many as fit.  Kernel timing (volly_gpu_set_profiling) is not recorded for these calls.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams,
+ * threads or scenes) race; calls queued on one stream do not. */
+int volume_gpu_render_device_noalloc(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames,
+                                     const volly_outputs *outs, void *hip_stream);
+
 /* Scene preparation on the device: the voxelization of Vol_LOD_Set's constructor
  * (main.cpp:23-50) for one target resolution -- rasterizeVoxelMapFromPoly
  * (PLYfileReader.cpp:218-321) with t_c_intersection (triangleCube.c:213-319),

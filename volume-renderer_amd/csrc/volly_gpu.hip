@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -17,10 +18,43 @@ namespace vimpl {
 thread_local std::string g_err;
 }
 
+// ---- scratch of volume_gpu_render_device_noalloc ------------------------------------------
+// The entry point for callers that cannot allocate keeps what volume_gpu_render_device takes from
+// hipMalloc -- the frame descriptors of one launch and its direction checkpoints -- in this array.
+// Every GPU the library runs on holds its own copy (at its own address) until the process ends;
+// host code never uses the array's name as an address, only what hipGetSymbolAddress returned for
+// the device in question (noalloc_scratch below).
+namespace {
+constexpr size_t kNoAllocDescBytes = 4096;                 // vk::kInlineFrames descriptors of 176 B, padded
+constexpr size_t kNoAllocCkptFloats = (size_t)8 << 20;     // 32 MiB of direction checkpoints: 6 * ceil(tile_w / 8) * tile_h floats per frame
+constexpr int kMaxDevices = 64;
+}
+static __device__ __align__(256) unsigned char scratch[kNoAllocDescBytes + kNoAllocCkptFloats * sizeof(float)];
+
 using namespace vimpl;
 
 namespace {
 constexpr int kFrameChunk = 32;     // frames per launch (bounds the checkpoint scratch)
+static_assert(sizeof(volly_frame_desc) * vk::kInlineFrames <= kNoAllocDescBytes, "descriptor part of the static scratch");
+
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[kMaxDevices] = {};
+
+// device address of `scratch` on `device`, which must be the current device; resolved once per device
+void *noalloc_scratch(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        g_scratch_ptr[device] = p;
+    }
+    return g_scratch_ptr[device];
+}
 }
 
 namespace vimpl {
@@ -126,6 +160,11 @@ int new_scene(int device, volly_gpu_scene **out)
     volly_gpu_scene *s = new (std::nothrow) volly_gpu_scene();
     if (!s) return fail(VOLLY_E_NOMEM, "host allocation failed");
     s->device = device;
+    {   // set-up is where the static scratch of the entry point that allocates nothing is looked up
+        // (once per device, with that device current); a failure is reported by that entry point only
+        DeviceGuard g(device);
+        if (g.ok) s->noalloc_scratch = noalloc_scratch(device);
+    }
     *out = s;
     return VOLLY_OK;
 }
@@ -214,28 +253,44 @@ size_t occupancy_probe_lds()
     return n;
 }
 
+size_t checkpoint_floats(const volly_frame_desc &f, int n)
+{
+    return (size_t)n * (size_t)((f.tile_w + vk::kCkpt - 1) / vk::kCkpt) * (size_t)f.tile_h * 6;
+}
+
+// One launch of the pre-pass and the frame kernel for n <= kFrameChunk frames.  fixed_frames /
+// fixed_ckpt: scratch handed in by the entry point that allocates nothing (then n <=
+// vk::kInlineFrames, the checkpoints fit, and this function calls no allocating routine);
+// null: the scene's own scratch, grown with hipMalloc as needed.
 int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size_t frame_offset, const volly_outputs *outs,
-                 hipStream_t stream)
+                 hipStream_t stream, volly_frame_desc *fixed_frames = nullptr, float *fixed_ckpt = nullptr)
 {
     const int tw = frames[0].tile_w, th = frames[0].tile_h;
-    const int groups = (tw + vk::kCkpt - 1) / vk::kCkpt;
-    const size_t need = (size_t)n * groups * th * 6;
+    const size_t need = checkpoint_floats(frames[0], n);
     if (need >= (1ull << 31)) return fail(VOLLY_E_ARG, "render: sub-rectangles of more than ~2^30 pixels per launch");
-    if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, sizeof(volly_frame_desc) * kFrameChunk));
-    if (need > s->ckpt_floats) {
-        if (s->d_ckpt) { HIP_TRY(hipFree(s->d_ckpt)); s->d_ckpt = nullptr; s->ckpt_floats = 0; }
-        HIP_TRY(hipMalloc((void **)&s->d_ckpt, need * sizeof(float)));
-        s->ckpt_floats = need;
-    }
+    const bool no_alloc = fixed_frames != nullptr;
+    volly_frame_desc *d_frames = fixed_frames;
+    float *d_ckpt = fixed_ckpt;
+    if (!no_alloc) {
+        if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, sizeof(volly_frame_desc) * kFrameChunk));
+        if (need > s->ckpt_floats) {
+            if (s->d_ckpt) { HIP_TRY(hipFree(s->d_ckpt)); s->d_ckpt = nullptr; s->ckpt_floats = 0; }
+            HIP_TRY(hipMalloc((void **)&s->d_ckpt, need * sizeof(float)));
+            s->ckpt_floats = need;
+        }
+        d_frames = s->d_frames;
+        d_ckpt = s->d_ckpt;
+    } else if (n > vk::kInlineFrames || need > kNoAllocCkptFloats)
+        return fail(VOLLY_E_ARG, "render: batch does not fit the static scratch");
     const dim3 pre_grid((unsigned)((th + 63) / 64), (unsigned)n, 6);
     if (n <= vk::kInlineFrames) {                         // descriptors as kernel arguments: no copy ahead of the pre-pass
         vk::FrameBatch batch;
         std::memcpy(batch.f, frames, sizeof(volly_frame_desc) * (size_t)n);
         std::memset(batch.f + n, 0, sizeof(volly_frame_desc) * (size_t)(vk::kInlineFrames - n));
-        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, n, s->d_frames, s->d_ckpt);
+        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, n, d_frames, d_ckpt);
     } else {
-        HIP_TRY(hipMemcpyAsync(s->d_frames, frames, sizeof(volly_frame_desc) * (size_t)n, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(vk::direction_checkpoints, pre_grid, dim3(64), 0, stream, s->d_frames, n, s->d_ckpt);
+        HIP_TRY(hipMemcpyAsync(d_frames, frames, sizeof(volly_frame_desc) * (size_t)n, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(vk::direction_checkpoints, pre_grid, dim3(64), 0, stream, d_frames, n, d_ckpt);
     }
     HIP_TRY(hipGetLastError());
 
@@ -249,7 +304,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     o.pt_end = outs->pt_end ? outs->pt_end + 3 * px : nullptr;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (s->profiling) {                                   // the pair belongs to the scene from here on (destroy() frees it)
+    if (s->profiling && !no_alloc) {                      // the pair belongs to the scene from here on (destroy() frees it)
         HIP_TRY(hipEventCreate(&e0));
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(VOLLY_E_HIP, "render: hipEventCreate failed"); }
         s->events.emplace_back(e0, e1);
@@ -258,7 +313,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     dim3 grid((unsigned)((tw + vk::kBlockW * vk::kTilesPerWave - 1) / (vk::kBlockW * vk::kTilesPerWave)), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
     bool any_raytrace = false;
     for (int i = 0; i < n; ++i) any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
-    if (s->requeue && !any_raytrace) {
+    if (s->requeue && !any_raytrace && !no_alloc) {
         const size_t n_px = (size_t)n * tw * th;
         if (n_px >= (1ull << 32)) return fail(VOLLY_E_ARG, "render: more than 2^32 pixels per launch");
         if (n_px > s->queue_rays) {
@@ -273,7 +328,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         if (const char *e = std::getenv("VOLLY_REQUEUE_BUDGET")) budget = (uint32_t)std::max(std::atoi(e), 1);
         HIP_TRY(hipMemsetAsync(counts, 0, 8, stream));
         dim3 tiles((unsigned)((tw + vk::kTile - 1) / vk::kTile), (unsigned)((th + vk::kTile - 1) / vk::kTile), (unsigned)n);
-        hipLaunchKernelGGL(vk::render_frames_budget, tiles, dim3(64), 0, stream, s->target, s->low, s->d_frames, s->d_ckpt, o, q[0], budget);
+        hipLaunchKernelGGL(vk::render_frames_budget, tiles, dim3(64), 0, stream, s->target, s->low, d_frames, d_ckpt, o, q[0], budget);
         HIP_TRY(hipGetLastError());
         // every round continues the rays the previous one parked; the span doubles, and the last
         // round runs to the iteration cap, where every ray ends
@@ -283,28 +338,28 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
             const bool last = (uint64_t)iter0 + span >= s->target.cap;
             const uint32_t iter_end = last ? 0xFFFFFFFFu : iter0 + span;
             HIP_TRY(hipMemsetAsync(q[cur ^ 1].count, 0, 4, stream));
-            hipLaunchKernelGGL(vk::continue_rays, dim3(cont_blocks), dim3(64), 0, stream, s->target, s->d_frames, (uint32_t)(tw * th), q[cur],
+            hipLaunchKernelGGL(vk::continue_rays, dim3(cont_blocks), dim3(64), 0, stream, s->target, d_frames, (uint32_t)(tw * th), q[cur],
                                q[cur ^ 1], o, iter0, iter_end);
             HIP_TRY(hipGetLastError());
             cur ^= 1;
             if (last) break;
         }
-    } else if (s->refill && !any_raytrace) {
+    } else if (s->refill && !any_raytrace && !no_alloc) {
         const unsigned tiles = (unsigned)((tw + vk::kTile - 1) / vk::kTile) * (unsigned)((th + vk::kTile - 1) / vk::kTile);
         const unsigned waves = (tiles + vk::kRaysPerWave / 64 - 1) / (vk::kRaysPerWave / 64);
         hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
-                           s->low, s->d_frames, s->d_ckpt, o);
+                           s->low, d_frames, d_ckpt, o);
     } else if (s->is_svo)
-        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), occupancy_probe_lds(), stream, s->target, s->svo, s->low, s->d_frames,
-                           s->d_ckpt, o);
+        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), occupancy_probe_lds(), stream, s->target, s->svo, s->low, d_frames,
+                           d_ckpt, o);
     else if (any_raytrace)
         hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low,
-                           s->d_frames, s->d_ckpt, o);
+                           d_frames, d_ckpt, o);
     else
-        hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, s->d_frames,
-                           s->d_ckpt, o);
+        hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
+                           d_ckpt, o);
     HIP_TRY(hipGetLastError());
-    if (s->profiling) HIP_TRY(hipEventRecord(e1, stream));
+    if (e1) HIP_TRY(hipEventRecord(e1, stream));
     return VOLLY_OK;
 }
 
@@ -439,6 +494,35 @@ int volume_gpu_render_device(volly_gpu_scene *scene, const volly_frame_desc *fra
     for (int first = 0; first < n_frames; first += kFrameChunk) {
         const int n = std::min(kFrameChunk, n_frames - first);
         if ((rc = render_chunk(scene, frames + first, n, (size_t)first, outs, stream))) return rc;
+    }
+    return VOLLY_OK;
+}
+
+int volume_gpu_render_device_noalloc(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames, const volly_outputs *outs,
+                                     void *hip_stream)
+{
+    int rc = validate_frames(scene, frames, n_frames);
+    if (rc) return rc;
+    if (!outs) return fail(VOLLY_E_ARG, "render: outs is null");
+    DeviceGuard g(scene->device);
+    if (!g.ok) return fail(VOLLY_E_HIP, "hipSetDevice failed");
+    if (!scene->noalloc_scratch) scene->noalloc_scratch = noalloc_scratch(scene->device);     // first call on this device
+    if (!scene->noalloc_scratch) return fail(VOLLY_E_HIP, "volume_gpu_render_device_noalloc: hipGetSymbolAddress(scratch) failed");
+    const size_t per_frame = checkpoint_floats(frames[0], 1);
+    if (per_frame > kNoAllocCkptFloats)
+        return fail(VOLLY_E_ARG, "volume_gpu_render_device_noalloc: one sub-rectangle needs " + std::to_string(per_frame * sizeof(float)) +
+                                     " bytes of direction checkpoints (6 * ceil(tile_w / 8) * tile_h floats), the static scratch holds " +
+                                     std::to_string(kNoAllocCkptFloats * sizeof(float)) + ": render row bands, or use volume_gpu_render_device");
+    volly_frame_desc *d_frames = (volly_frame_desc *)scene->noalloc_scratch;
+    float *d_ckpt = (float *)((unsigned char *)scene->noalloc_scratch + kNoAllocDescBytes);
+    const int chunk = (int)std::min<size_t>((size_t)vk::kInlineFrames, kNoAllocCkptFloats / per_frame);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    // chunks follow each other on `stream`, so a chunk's pre-pass overwrites the scratch only after
+    // the previous chunk's frame kernel has finished with it; nothing in it has to start at zero
+    // (descriptors and checkpoints are written in full before they are read)
+    for (int first = 0; first < n_frames; first += chunk) {
+        const int n = std::min(chunk, n_frames - first);
+        if ((rc = render_chunk(scene, frames + first, n, (size_t)first, outs, stream, d_frames, d_ckpt))) return rc;
     }
     return VOLLY_OK;
 }

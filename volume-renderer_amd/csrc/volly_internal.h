@@ -64,6 +64,7 @@ struct volly_gpu_scene {
     void *d_planes = nullptr;       // staging of the synchronous entry point
     size_t plane_bytes = 0;
     hipStream_t s_render = nullptr, s_copy = nullptr;   // pinned-output path: render and copy-back overlap
+    void *noalloc_scratch = nullptr; // this device's copy of the static scratch (volume_gpu_render_device_noalloc), not owned
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;

@@ -36,6 +36,7 @@ _sig = {
     "volly_gpu_tricube": (C.c_int, [C.c_int, _vp, C.c_int64, _vp]),
     "volume_gpu_render": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs)]),
     "volume_gpu_render_device": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs), _vp]),
+    "volume_gpu_render_device_noalloc": (C.c_int, [_vp, C.POINTER(FrameDesc), C.c_int, C.POINTER(Outputs), _vp]),
     "volly_gpu_host_alloc": (_vp, [C.c_size_t]),
     "volly_gpu_host_free": (None, [_vp]),
     "volly_gpu_set_profiling": (C.c_int, [_vp, C.c_int]),
@@ -196,6 +197,12 @@ class GpuScene:
         arr, n = _frames_array(frames)
         outs = Outputs(*[ptrs.get(p) for p in ALL_PLANES])
         _check(lib.volume_gpu_render_device(self._h, arr, n, C.byref(outs), stream), "volume_gpu_render_device")
+
+    def render_device_noalloc(self, frames, ptrs, stream=None):
+        """volume_gpu_render_device_noalloc: the same, scratch from the library's static device array."""
+        arr, n = _frames_array(frames)
+        outs = Outputs(*[ptrs.get(p) for p in ALL_PLANES])
+        _check(lib.volume_gpu_render_device_noalloc(self._h, arr, n, C.byref(outs), stream), "volume_gpu_render_device_noalloc")
 
     def set_profiling(self, on=True):
         _check(lib.volly_gpu_set_profiling(self._h, int(on)), "volly_gpu_set_profiling")
