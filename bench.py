@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- primary Mrays/s of the MI355X traversal path on BASELINE.json's
-config 2 (dragon.off voxelized at 512^3, octree target, 1920x1080 frames).
+"""bench.py -- primary Mrays/s of the MI355X traversal path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 0..5]
 
-One "step" = one pass of the hot path over one batch of `--views` orbit views on
-every rank (weak scaling: per-GPU work is fixed, views are split round-robin over
-the ranks, scene replicated, no collective on the data path).  Inputs (octree,
-low grid) are resident in HBM before the timed region; outputs (rgba8, hit
-index, step counts, depth: 20 B/ray) stay in HBM.  Rank 0 prints ONE JSON line.
+Default workload (--config 0) is BASELINE.json's north-star target: dragon.off voxelized at
+1024^3, octree target, 256^3 beam grid, 3840x2160 frames, the reference's live per-pixel call
+(raycast_beamOpt, main.cpp:260 -> main.cpp:163-166).  --config 1..5 are BASELINE.json's configs.
+
+One "step" = one pass of the hot path over one batch of `--views` orbit views on every rank
+(weak scaling: per-GPU work is fixed, views are dealt round-robin to the ranks, scene replicated,
+no collective on the data path; --config 4 / --split is the single-frame row-band split with one
+gather).  Inputs (octree, low grid) are resident in HBM before the timed region; outputs (rgba8,
+hit index, step counts, depth: 20 B/ray) stay in HBM.  Rank 0 prints ONE JSON line.
+
+--gpus N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts N ranks
+itself, one per GPU, before it touches HIP or torch, relays rank 0's JSON line and exits with the
+worst exit code.  Under torch.distributed.run it is one of the ranks; WORLD_SIZE != --gpus is an error.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,15 +29,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMDS = 1024                 # 256 CUs x 4 SIMDs
 ORBIT_VIEWS = 4096             # SURVEY 8d config 5 orbit
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r02.json")   # written by profiles/summarize.py from rocprofv3 --pmc passes
 
-# BASELINE.json configs -> workload parameters (scene "noise" = volume_gpu_generate_noise, p = 1/256)
+# workload parameters (scene "noise" = volume_gpu_generate_noise; several scenes = alternate per step)
 PRESETS = {
+    0: dict(scene="dragon.off", res=1024, target="svo", width=3840, height=2160, views=4, radius=1.0, split=False),   # north-star target
     1: dict(scene="teapot.off", res=128, target="svo", width=640, height=480, views=64, radius=1.0, split=False),
     2: dict(scene="dragon.off", res=512, target="svo", width=1920, height=1080, views=16, radius=1.0, split=False),
     3: dict(scene="noise", res=1024, target="dense", width=3840, height=2160, views=2, radius=1.1, split=False),
     4: dict(scene="galleon.ply", res=2048, target="svo", width=7680, height=4320, views=1, radius=1.0, split=True),
-    5: dict(scene="stratocaster.ply", res=1024, target="svo", width=1920, height=1080, views=16, radius=1.2, split=False),
+    5: dict(scene="stratocaster.ply,dragon.off", res=1024, target="svo", width=1920, height=1080, views=16, radius=1.2, split=False),
 }
 
 
@@ -37,15 +49,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(PRESETS),
-                    help="BASELINE.json config number (default 2, the config the metric is quoted on)")
+    ap.add_argument("--config", type=int, default=0, choices=sorted(PRESETS),
+                    help="0 = the north-star target workload (default); 1..5 = BASELINE.json's configs")
     ap.add_argument("--views", type=int, default=None, help="orbit views per step per GPU")
-    ap.add_argument("--scene", default=None)
+    ap.add_argument("--scene", default=None, help="asset file name(s), comma separated (alternate per step), or 'noise'")
     ap.add_argument("--res", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--radius", type=float, default=None)
     ap.add_argument("--target", choices=["svo", "dense"], default=None)
+    ap.add_argument("--noise-log2-inv-p", type=int, default=8,
+                    help="noise scene: a voxel is filled with probability 2^-n (config 3: 8 = 1/256; sweeps 6 and 10)")
     ap.add_argument("--split", action="store_true", default=None,
                     help="one frame per step split into row bands over the ranks + gather to rank 0 (config 4)")
     ap.add_argument("--mode", choices=["beam", "naive"], default="beam",
@@ -55,6 +69,9 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="collective backend; gloo + --force-device rehearses the N>1 paths on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=None, help="use this GPU on every rank (rehearsal only)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous rehearsal without a GPU: ranks meet (use --backend gloo), run the barrier and "
+                         "the max-over-ranks reduction, rank 0 prints the JSON line with value null; nothing is rendered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the workload timed on the CPU oracle (0 = auto)")
     args = ap.parse_args()
@@ -64,48 +81,109 @@ def parse():
     return args
 
 
+def launch_ranks(n):
+    """Start n fresh ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment).  The parent has made no HIP or torch call; it only waits and relays."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        worst = max(worst, abs(rc))
+    return worst
+
+
+def pmc_entry(key, rays_per_launch):
+    """Counter figures of this workload's dominant kernel from a separate rocprofv3 --pmc run
+    (profiles/run_pmc.sh + profiles/summarize.py), or None when that run was not made / had another shape."""
+    try:
+        e = json.load(open(PMC_FILE)).get(key)
+    except Exception:
+        return None
+    if not e or e.get("rays_per_launch") != rays_per_launch:
+        return None
+    return e
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))          # before any torch / HIP call in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: start it as `python bench.py --gpus N` "
+              f"or under torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
-    from __graft_entry__ import load_package
-    vra = load_package()
 
     if args.force_device is not None:
         local_rank = args.force_device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
+        if not args.dry_run:
+            torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+
+    if args.dry_run:                               # plumbing only: the N>1 launch path without a GPU
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "primary Mrays/s", "value": None, "unit": "Mrays/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                              "max_over_ranks_probe": float(t.item())}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    from __graft_entry__ import load_package
+    vra = load_package()
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where collective operands live
 
-    # ---- scene: host voxelization + octree build (or device-side noise), one upload to HBM ----
+    # ---- scenes: host voxelization + octree build (or device-side noise), one upload to HBM ----
     t0 = time.time()
     want_dense = args.target == "dense"
-    scene = None
-    if args.scene == "noise":
-        gpu = vra.GpuScene.noise(args.res, seed=1, threshold=1 << 24, device=local_rank)      # p = 2^24 / 2^32 = 1/256
-        data = f"synthetic {args.res}^3 noise volume generated on the device (p = 1/256), synthetic orbit cameras"
-    else:
-        threads = 0 if world == 1 else max(2, 16 // min(world, 8))
-        scene = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", args.scene), args.res, dense=want_dense,
-                                        svo=not want_dense, threads=threads)
-        if want_dense:
-            gpu = vra.GpuScene.upload_dense(scene.target, scene.low, device=local_rank)
+    names = args.scene.split(",")
+    host_scenes, gpus = [], []
+    for name in names:
+        if name == "noise":
+            gpus.append(vra.GpuScene.noise(args.res, seed=1, threshold=1 << (32 - args.noise_log2_inv_p), device=local_rank))
+            host_scenes.append(None)
         else:
-            gpu = vra.GpuScene.upload_svo(scene.svo, scene.low, device=local_rank)
-        data = f"bundled asset ({args.scene}) voxelized on the host, synthetic orbit cameras"
+            threads = 0 if world == 1 else max(2, 16 // min(world, 8))
+            sc = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", name), args.res, dense=want_dense, svo=not want_dense, threads=threads)
+            gpus.append(vra.GpuScene.upload_dense(sc.target, sc.low, device=local_rank) if want_dense
+                        else vra.GpuScene.upload_svo(sc.svo, sc.low, device=local_rank))
+            host_scenes.append(sc)
+    if names == ["noise"]:
+        data = f"synthetic {args.res}^3 noise volume generated on the device (p = 2^-{args.noise_log2_inv_p}), synthetic orbit cameras"
+    else:
+        data = f"bundled asset(s) {args.scene} voxelized on the host, synthetic orbit cameras"
     size_hi, size_lo = (args.res,) * 3, (args.res // 4,) * 3
     setup_s = time.time() - t0
+    scene, gpu = host_scenes[0], gpus[0]
 
     # the same scene prepared on the device (volume_gpu_voxelize), outside the timed region: how
     # long it takes and whether octree / grids equal the host pipeline's (reported, rank 0)
@@ -113,14 +191,14 @@ def main():
     if scene is not None and rank == 0 and not args.no_device_prepare:
         try:
             import numpy as np
-            mesh = vra.HostMesh(os.path.join(ROOT, "assets", args.scene), 2)
+            mesh = vra.HostMesh(os.path.join(ROOT, "assets", names[0]), 2)
             best = None
-            for _ in range(2):
+            for i in range(2):
                 t1 = time.time()
                 g2 = vra.GpuScene.voxelize(mesh.desc, args.res, dense=want_dense, svo=not want_dense, device=local_rank)
                 dt = time.time() - t1
                 best = dt if best is None else min(best, dt)
-                if _ == 0:
+                if i == 0:
                     g2.close()
             same = bool(np.array_equal(g2.read_low_voxels(), vra.host.dense_view(scene.low).reshape(-1, 8)))
             if want_dense:
@@ -144,9 +222,9 @@ def main():
         y0, rows = vra.shard.band_rows(H, rank, world)
     else:
         y0, rows = 0, H
-    names = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")
+    plane_names = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")
     planes = {p: torch.empty((B, rows, W), dtype=torch.float32 if p == "depth" else torch.int32, device=dev)
-              for p in names}
+              for p in plane_names}
     ptrs = {p: t.data_ptr() for p, t in planes.items()}
     stream = torch.cuda.current_stream(dev)
 
@@ -163,29 +241,34 @@ def main():
     all_frames = [step_frames(s) for s in range(args.warmup + args.steps)]
     assembled = [None]
 
-    def run(frames):
-        gpu.render_device(frames, ptrs, stream=stream.cuda_stream)
+    def run(s):
+        gpus[s % len(gpus)].render_device(all_frames[s], ptrs, stream=stream.cuda_stream)
         if split:      # frame assembly on rank 0: the one collective of the path (RCCL gather over xGMI)
             assembled[0] = vra.shard.gather_bands(planes["rgba8"][0].to(coll_dev), H, W, rank, world, dist, dst=0)
 
     for s in range(args.warmup):
-        run(all_frames[s])
+        run(s)
     torch.cuda.synchronize(dev)
-    gpu.kernel_time()                       # drop warm-up events
-    gpu.set_profiling(True)                 # HIP events around every traversal-kernel launch, on `stream`
+    for g in gpus:
+        g.kernel_time()                     # drop warm-up events
+        g.set_profiling(True)               # HIP events around every traversal-kernel launch, on `stream`
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t_start = time.perf_counter()
     for s in range(args.warmup, args.warmup + args.steps):
-        run(all_frames[s])
+        run(s)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    kern_ms, launches = gpu.kernel_time()
-    gpu.set_profiling(False)
+    kern_ms = launches = 0
+    for g in gpus:
+        ms, n = g.kernel_time()
+        kern_ms += ms
+        launches += n
+        g.set_profiling(False)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
@@ -198,7 +281,7 @@ def main():
     sum_lo = sum_hi = hits = 0
     rays_per_launch = B * rows * W
     for s in range(args.warmup, args.warmup + args.steps):
-        gpu.render_device(all_frames[s], ptrs, stream=stream.cuda_stream)
+        gpus[s % len(gpus)].render_device(all_frames[s], ptrs, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         lo = int(planes["steps_lo"].sum(dtype=torch.int64).item())
         hi = int(planes["steps_hi"].sum(dtype=torch.int64).item())
@@ -211,7 +294,7 @@ def main():
         last = args.warmup + args.steps - 1
         full = vra.orbit_frames([last % ORBIT_VIEWS], ORBIT_VIEWS, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
         alone = torch.empty((1, H, W), dtype=torch.int32, device=dev)
-        gpu.render_device(full, {"rgba8": alone.data_ptr()}, stream=stream.cuda_stream)
+        gpus[last % len(gpus)].render_device(full, {"rgba8": alone.data_ptr()}, stream=stream.cuda_stream)
         torch.cuda.synchronize(dev)
         assembled_ok = bool(torch.equal(assembled[0].to(dev), alone[0]))
 
@@ -219,6 +302,9 @@ def main():
     mrays = rays_per_step * args.steps / elapsed / 1e6
     par = (f"one frame split into {world} row bands + gather of rgba8 to rank 0" if split
            else f"view-parallel x{world}, scene replicated, no collective")
+    label = "north-star target" if args.config == 0 else f"BASELINE config {args.config}"
+    if args.scene == "noise" and args.noise_log2_inv_p != 8:
+        label += f", p = 2^-{args.noise_log2_inv_p} sweep"
     out = {
         "metric": "primary Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -226,13 +312,14 @@ def main():
         "higher_is_better": True, "scaling": "strong" if split else "weak", "vs_baseline": None,
         "dtype": "f32", "data": data,
         "config": {"workload": f"{args.scene} at {args.res}^3 {args.target} target, low grid {args.res // 4}^3, "
-                               f"{W}x{H} frames, {args.mode} mode (BASELINE config {args.config})",
+                               f"{W}x{H} frames, {args.mode} mode ({label})",
                    "views_per_step_per_gpu": B, "rays_per_step": rays_per_step,
                    "orbit_radius": args.radius, "planes_written": 5, "parallelism": par,
                    "mean_steps_lo": round(sum_lo / (rays_per_launch * args.steps), 3),
                    "mean_steps_hi": round(sum_hi / (rays_per_launch * args.steps), 3),
                    "hit_fraction": round(hits / (rays_per_launch * args.steps), 4),
-                   "scene_setup_s": round(setup_s, 2), "scene_device_mib": gpu.info(7)},
+                   "dda_loop": ", ".join(g.dda_loops() for g in gpus),
+                   "scene_setup_s": round(setup_s, 2), "scene_device_mib": sum(g.info(7) for g in gpus)},
     }
     if assembled_ok is not None:
         out["config"]["assembled_frame_equals_single_gpu_frame"] = assembled_ok
@@ -242,37 +329,51 @@ def main():
         avg_ms = kern_ms / launches
         alg_per_launch = alg_bytes / launches
         achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.config == 2 and args.mode == "beam" and not split:
-            try:     # measured with rocprofv3 --pmc on this same default workload (see the file's comment)
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": {1: "vk::render_frames_refill", 2: "vk::render_frames_budget + vk::continue_rays"}.get(
-                               gpu.info(8), "vk::render_frames<%s>" % ("true" if args.target == "svo" else "false")),
-                           "kernel_avg_ms": round(avg_ms, 4), "launches": launches,
-                           "algorithmic_bytes_per_launch": int(alg_per_launch)}
+        kernel = "vk::render_frames<%s>" % ("true" if args.target == "svo" else "false")
+        # `roofline` is the contractual figure: ALGORITHMIC bytes (the reference layout's 8 B per executed
+        # sample) over the kernel time measured here with HIP events.  The kernel does not move
+        # those bytes -- it walks 1-bit occupancy words that stay in cache -- so `measured` carries what
+        # binds it (vector-ALU issue) and the real HBM rate, from rocprofv3 --pmc passes of this same
+        # workload made in separate runs (counters cannot be read inside this process).
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
+                "kernel_avg_ms": round(avg_ms, 4), "launches": launches,
+                "algorithmic_bytes_per_launch": int(alg_per_launch)}
+        pmc = pmc_entry(f"config{args.config}:{args.mode}" + ("" if args.noise_log2_inv_p == 8 else f":p{args.noise_log2_inv_p}"),
+                        rays_per_launch) if not split or world == 1 else None
+        if pmc:
+            roof["traffic"] = pmc["hbm_bytes_per_launch"]
+            roof["traffic_source"] = pmc["source"] + " (rocprofv3 --pmc, separate run of this workload; 2*FETCH_SIZE + WRITE_SIZE)"
+            real_gbs = pmc["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            out["measured"] = {
+                "binding_resource": "vector-ALU issue",
+                "valu_issue_frac": pmc["valu_issue_frac"],
+                "valu_issue_frac_def": "SQ_INSTS_VALU / (1024 SIMDs * kernel cycles / 2): share of the one-wave64-instruction-per-2-cycles issue peak",
+                "hbm_real_gbs": round(real_gbs, 1), "hbm_real_frac": round(real_gbs / HBM_PEAK_GBS, 4),
+                "l2_read_hit_rate": pmc["l2_read_hit_rate"], "waves_per_simd": pmc["waves_per_simd"],
+                "active_lanes_avg": pmc["active_lanes_avg"], "pmc_kernel_avg_ms": pmc["kernel_avg_ms"],
+                "source": pmc["source"]}
+        out["roofline"] = roof
 
     # ---- CPU baseline: the oracle, one thread (the reference is single threaded), bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline and scene is not None:
         from __graft_entry__ import load_oracle
         ora = load_oracle()
         n_cpu = args.cpu_frames or max(1, min(8, int(round(16e6 / (W * H)))))
-        frames = all_frames[args.warmup]
+        s0 = args.warmup + (-args.warmup) % len(gpus)          # a timed step that rendered names[0]
+        frames = all_frames[s0 if s0 < len(all_frames) else args.warmup]
         kw = dict(low=scene.low, target=scene.target) if want_dense else dict(low=scene.low, svo=scene.svo)
         t1 = time.perf_counter()
         for i in range(n_cpu):
             ora.render_frame(frames[i % B], threads=1, **kw)
         cpu_s = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": round(n_cpu * rows * W / cpu_s / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
-                               "sample": f"{n_cpu} frame(s) of the first timed step ({n_cpu * rows * W} rays), "
+                               "sample": f"{n_cpu} frame(s) of a timed step of {names[0]} ({n_cpu * rows * W} rays), "
                                          f"scalar C oracle, gcc -O3 -mavx -ffp-contract=off, {cpu_s:.1f} s"}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    gpu.close()
+    for g in gpus:
+        g.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -237,7 +237,13 @@ int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leav
 /* Scene facts: 0 sx, 1 sy, 2 sz, 3 is_svo, 4 has_low, 5 low sx, 6 device,
  * 7 device bytes held (MiB), 8 frame kernel (0 tile per wavefront, 1 ray refill, 2 budgeted rounds with parked rays),
  * 9 target grid uses the 16^3 region level, 10 octree nodes, 11 octree leaves,
- * 12 octree depth, 13 a dense target grid is held. */
+ * 12 octree depth, 13 a dense target grid is held,
+ * 14 the DDA loop the TARGET grid is traversed with: 0 = octree (not a dense traversal), 1 = the assembly
+ *    loop over 16^3 regions and 4^3 bricks, 2 = the assembly loop over bricks only (grids whose regions
+ *    nearly all hold voxels), 3 = the fully checked compiled loop -- taken by every grid with an axis
+ *    that is not a multiple of 16 or is larger than 1024, measured ~16 % slower; wavefronts holding a
+ *    ray with a zero / denormal / NaN direction component take loop 3 whatever the grid,
+ * 15 the same for the LOW (beam) grid, 0 = no low grid. */
 int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
 
 void        volly_gpu_free(volly_gpu_scene *scene);

@@ -34,6 +34,7 @@ def main():
     a = ap.parse_args()
     vra = load_package()
     p = dict(B.PRESETS[a.config])
+    p["scene"] = p["scene"].split(",")[0]
     if a.views:
         p["views"] = a.views
     res, W, H, nv = p["res"], p["width"], p["height"], p["views"]

@@ -1,8 +1,23 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (written by profiles/run_profiles.sh) into profiles/<tag>/:
-kernel_stats.csv (rocprofv3 --kernel-trace --stats) and pmc_summary.csv (per-launch mean of every
-counter for the render_frames kernel).  usage: python profiles/summarize.py <tag>"""
-import csv, glob, os, shutil, sys
+"""Condense gpurun_out/prof_<tag>/<workload key>/ (written by profiles/run_pmc.sh) into
+profiles/<tag>/:
+  <key>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of that workload
+  pmc_summary.csv          per-launch mean of every counter of the frame kernel, one block per workload,
+                           followed by the derived figures
+  and profiles/pmc_<tag>.json, which bench.py attaches to its JSON line (roofline.traffic, `measured`).
+
+Derived figures (per launch of vk::render_frames<...>):
+  cycles            = GRBM_GUI_ACTIVE / 8                       (the counter sums the 8 XCDs)
+  hbm_bytes         = (2 * FETCH_SIZE + WRITE_SIZE) * 1024      (MI355X_MICROARCH.md, HBM: gfx950 tallies a
+                      128-B read request as 64 B -- doubled; WRITE_SIZE exact; both are taken at the L2's
+                      memory side, so Infinity-Cache hits are included: an upper bound on HBM bytes)
+  valu_issue_frac   = SQ_INSTS_VALU / (1024 SIMDs * cycles / 2) (share of one wave64 VALU instruction per 2 cycles)
+  l2_read_hit_rate  = 1 - TCC_EA0_RDREQ_sum / TCC_READ_sum      (reads only: every read miss leaves the L2 as one
+                      memory-side read request; the store segments, which dominate TCC_REQ, are left out)
+  waves_per_simd    = 4 * SQ_WAVE_CYCLES / (1024 * cycles)      (SQ_WAVE_CYCLES counts in units of 4 cycles)
+  active_lanes_avg  = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU
+usage: python profiles/summarize.py <tag>"""
+import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 tag = sys.argv[1]
@@ -10,20 +25,73 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
-rows = []
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
-    acc = defaultdict(lambda: defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, cs in acc.items():
-        if "render_frames" not in k and "direction_checkpoints" not in k:
-            continue
-        for c, v in cs.items():
-            rows.append((k, c, len(v), sum(v) / len(v)))
+summary, table = {}, []
+for kdir in sorted(glob.glob(os.path.join(src, "*", ""))):
+    key = os.path.basename(kdir.rstrip("/"))
+    stats = glob.glob(os.path.join(kdir, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    if not stats:
+        continue
+    shutil.copy(stats[0], os.path.join(dst, f"{key}_kernel_stats.csv"))
+    kern_ms = None
+    for r in csv.DictReader(open(stats[0])):
+        if "render_frames" in r["Name"]:
+            kern_ms = float(r["AverageNs"]) / 1e6
+            kname = r["Name"].split("(")[0]
+            break
+    bench = {}
+    try:
+        bench = json.loads(open(os.path.join(kdir, "bench_line.json")).readline())
+        json.dump(bench, open(os.path.join(dst, f"{key}_bench_under_rocprof.json"), "w"))
+    except Exception:
+        pass
+    c = {}
+    for f in sorted(glob.glob(os.path.join(kdir, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+        acc = defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "render_frames" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for name, v in acc.items():
+            c[name] = (sum(v) / len(v), len(v))
+    if not c:
+        continue
+    g = lambda n: c[n][0] if n in c else None
+    d = {}
+    cycles = g("GRBM_GUI_ACTIVE") / 8 if g("GRBM_GUI_ACTIVE") else None
+    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+        d["hbm_bytes_per_launch"] = int((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024)
+    if cycles and g("SQ_INSTS_VALU"):
+        d["kernel_cycles"] = round(cycles)
+        d["valu_issue_frac"] = round(g("SQ_INSTS_VALU") / (1024 * cycles / 2), 4)
+    if g("TCC_READ_sum") and g("TCC_EA0_RDREQ_sum") is not None:
+        d["l2_read_hit_rate"] = round(max(0.0, 1 - g("TCC_EA0_RDREQ_sum") / g("TCC_READ_sum")), 4)
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
+        d["l2_hit_rate_all_requests"] = round(g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
+    if cycles and g("SQ_WAVE_CYCLES"):
+        d["waves_per_simd"] = round(4 * g("SQ_WAVE_CYCLES") / (1024 * cycles), 2)
+    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_INSTS_VALU"):
+        d["active_lanes_avg"] = round(g("SQ_THREAD_CYCLES_VALU") / g("SQ_INSTS_VALU"), 1)
+    if cycles and g("TA_BUSY_avr"):
+        d["ta_busy_frac"] = round(g("TA_BUSY_avr") / cycles, 3)
+    d["kernel_avg_ms"] = round(kern_ms, 4) if kern_ms else None
+    d["kernel"] = kname if kern_ms else None
+    if kern_ms and "hbm_bytes_per_launch" in d:
+        d["hbm_real_gbs_under_rocprof"] = round(d["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1)
+    cfg = bench.get("config", {})
+    d["rays_per_launch"] = cfg.get("rays_per_step")
+    d["workload"] = cfg.get("workload")
+    d["source"] = f"profiles/{tag}/pmc_summary.csv [{key}]"
+    d["bench_args"] = open(os.path.join(kdir, "bench_args.txt")).read().strip() if os.path.exists(os.path.join(kdir, "bench_args.txt")) else None
+    # key of bench.py's lookup: config<N>:<mode>[:p<n>]
+    summary[key.replace("_", ":")] = d
+    for name in sorted(c):
+        table.append((key, name, c[name][1], f"{c[name][0]:.1f}"))
+    for name in sorted(d):
+        if isinstance(d[name], (int, float)):
+            table.append((key, "derived:" + name, "", d[name]))
 with open(os.path.join(dst, "pmc_summary.csv"), "w") as o:
-    o.write("kernel,counter,launches,mean_per_launch\n")
-    for r in rows:
-        o.write(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]:.1f}\n")
-        print(r)
+    o.write("workload,counter,launches,mean_per_launch\n")
+    for r in table:
+        o.write(",".join(str(x) for x in r) + "\n")
+json.dump(summary, open(os.path.join(root, "profiles", f"pmc_{tag}.json"), "w"), indent=1)
+for k, v in summary.items():
+    print(k, {n: v[n] for n in v if n not in ("workload", "source", "bench_args")})

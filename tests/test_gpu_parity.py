@@ -252,6 +252,61 @@ def test_config2_dragon512_full_frame(vra, ora):
     gpu.close()
 
 
+def test_north_star_dragon1024_octree_full_4k_frame(vra, ora):
+    """BASELINE.json's north-star target (bench.py's default workload): dragon.off at 1024^3,
+    octree target, 256^3 beam grid, one full 3840x2160 frame, in beam mode (raycast_beamOpt,
+    main.cpp:260 -> main.cpp:163-166) and in naive mode (main.cpp:261: the pure octree traversal
+    from the camera).  All five planes of all 8.3 M rays bit-exact against the oracle."""
+    scene = vra.HostScene.from_mesh(os.path.join(ASSETS, "dragon.off"), 1024, dense=False, svo=True)
+    hi, lo = (1024,) * 3, (256,) * 3
+    gpu = vra.GpuScene.upload_svo(scene.svo, scene.low)
+    assert gpu.dda_loops() == "target octree, low asm-regions"
+    for naive, view in ((False, 900), (True, 2900)):
+        f = vra.orbit_frames((view,), 4096, hi, lo, 3840, 2160, radius=1.0, naive=naive)[0]
+        got = gpu.render(f)
+        want = ora.render_frame(f, low=scene.low, svo=scene.svo, threads=16)
+        assert (want["hit_index"] != MISS).sum() > 400000
+        assert_planes_equal({k: v[0] for k, v in got.items()}, want, f"dragon1024 4K naive={naive}")
+        if naive:
+            assert int(want["steps_lo"].max()) == 0 and int(want["steps_hi"].max()) > 20
+        else:
+            assert int(want["steps_lo"].max()) > 200
+    gpu.close()
+    scene.close()
+
+
+def test_config5_dragon1024_from_the_scene_cache(vra, ora, tmp_path):
+    """BASELINE config 5's dragon half, and the on-disk scene cache on the GPU path (the
+    reference re-voxelizes every model at every start, main.cpp:369-387): dragon.off is voxelized
+    at 1024^3 on the device, the host pipeline's scene is saved and loaded back, the LOADED scene
+    is uploaded, and two 1920x1080 orbit views of it must equal both the oracle (on the loaded
+    scene) and the device-built scene's render."""
+    path = os.path.join(ASSETS, "dragon.off")
+    built = vra.HostScene.from_mesh(path, 1024, dense=False, svo=True)
+    cache = str(tmp_path / "dragon1024.volly")
+    built.save(cache)
+    assert os.path.getsize(cache) > 10 << 20
+    loaded = vra.HostScene.load(cache)
+    nb, lb = built.svo_arrays()
+    nl, ll = loaded.svo_arrays()
+    assert np.array_equal(nb.view(np.uint64), nl.view(np.uint64)) and np.array_equal(lb, ll)
+    built.close()
+    mesh = vra.HostMesh(path, 2)
+    gpu_dev = vra.GpuScene.voxelize(mesh.desc, 1024, dense=False, svo=True)
+    gpu = vra.GpuScene.upload_svo(loaded.svo, loaded.low)
+    ng, lg = gpu_dev.read_svo()
+    assert np.array_equal(ng.view(np.uint64), nl.view(np.uint64)) and np.array_equal(lg, ll)
+    frames = vra.orbit_frames((400, 3000), 4096, (1024,) * 3, (256,) * 3, 1920, 1080, radius=1.2)
+    got, got_dev = gpu.render(frames), gpu_dev.render(frames)
+    for i, f in enumerate(frames):
+        want = ora.render_frame(f, low=loaded.low, svo=loaded.svo, threads=16)
+        assert (want["hit_index"] != MISS).sum() > 50000
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"dragon1024 from the cache, view {i}")
+        assert_planes_equal({k: v[i] for k, v in got_dev.items()}, want, f"dragon1024 built on the device, view {i}")
+    for s_ in (gpu, gpu_dev, mesh, loaded):
+        s_.close()
+
+
 def test_config3_noise1024_rays_of_the_4k_frame(vra, ora):
     """BASELINE config 3: the device-generated 1024^3 noise volume (8 GiB of voxels) and its
     256^3 low grid, 3840x2160.  The volume is read back and the oracle traces two 256x144
@@ -350,102 +405,30 @@ def test_reference_style_state_example(vra, ora, tmp_path):
         assert np.array_equal(got, want[..., 1:4])
 
 
-def test_ray_refill_kernel(vra, ora, teapot64, sphere64, monkeypatch):
-    """The ray-refill frame kernel (opt-in, VOLLY_REFILL=1), on scenes where it meets every
-    case the tile kernel meets: beam and naive
-    frames, odd sizes, sub-rectangles, a batch, degenerate rays.  Same planes, bit for bit."""
-    monkeypatch.setenv("VOLLY_REFILL", "1")
-    for scene in (teapot64, sphere64):
-        hi, lo = _sizes(scene)
-        gpu = vra.GpuScene.upload_dense(scene.target, scene.low)
-        assert gpu.info(8) == 1
-        frames = list(vra.orbit_frames(range(0, 16, 5), 16, hi, lo, 150, 77, radius=0.9))
-        frames += list(vra.orbit_frames((3,), 16, hi, lo, 150, 77, radius=0.6, naive=True))
-        got = gpu.render(frames)
-        for i, f in enumerate(frames):
-            assert_planes_equal({k: v[i] for k, v in got.items()}, _oracle(ora, f, scene, "dense"), f"refill frame {i}")
-        sub = frames[1].copy()
-        sub.x0, sub.y0, sub.tile_w, sub.tile_h = 33, 9, 70, 41
-        assert_planes_equal({k: v[0] for k, v in gpu.render(sub).items()}, _oracle(ora, sub, scene, "dense"), "refill sub")
-        for row0, org in (((1, 0, 0), (-5, 32.5, 32.5)), ((0, 0, 0), (10, 10, 10)), ((1, 0, 0), (-5, -2.0, 32.5)),
-                          ((1, 1, 1), (-1, -1, -1))):
-            f = _manual_frame(vra, 16, 8, row0, (0, 0.25, 0), (0, 0, 0.25), org)
-            assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, _oracle(ora, f, scene, "dense"),
-                                f"refill degenerate {row0} {org}")
-        gpu.close()
-    monkeypatch.setenv("VOLLY_REFILL", "0")
-    gpu = vra.GpuScene.upload_dense(teapot64.target, teapot64.low)
-    assert gpu.info(8) == 0
-    gpu.close()
-
-
-@pytest.mark.parametrize("budget", ["1", "7", "40"])
-def test_budgeted_rounds_with_parked_rays(vra, ora, teapot64, sphere64, monkeypatch, budget):
-    """The frame kernels of volly_requeue.h (VOLLY_REQUEUE=1): rays are traced up to an iteration
-    budget, parked, and continued by follow-up launches.  Tiny budgets force many rounds and
-    rays parked at every stage of their life; the planes must equal the oracle's bit for bit,
-    for beam and naive frames, odd sizes, sub-rectangles, a batch and degenerate rays."""
-    monkeypatch.setenv("VOLLY_REQUEUE", "1")
-    monkeypatch.setenv("VOLLY_REQUEUE_BUDGET", budget)
-    for scene in (teapot64, sphere64):
-        hi, lo = _sizes(scene)
-        gpu = vra.GpuScene.upload_dense(scene.target, scene.low)
-        assert gpu.info(8) == 2
-        frames = list(vra.orbit_frames(range(0, 16, 5), 16, hi, lo, 150, 77, radius=0.9))
-        frames += list(vra.orbit_frames((3,), 16, hi, lo, 150, 77, radius=0.6, naive=True))
-        got = gpu.render(frames)
-        for i, f in enumerate(frames):
-            assert_planes_equal({k: v[i] for k, v in got.items()}, _oracle(ora, f, scene, "dense"), f"requeue frame {i}")
-        sub = frames[1].copy()
-        sub.x0, sub.y0, sub.tile_w, sub.tile_h = 33, 9, 70, 41
-        assert_planes_equal({k: v[0] for k, v in gpu.render(sub).items()}, _oracle(ora, sub, scene, "dense"), "requeue sub")
-        for row0, org in (((1, 0, 0), (-5, 32.5, 32.5)), ((0, 0, 0), (10, 10, 10)), ((1, 0, 0), (-5, -2.0, 32.5)),
-                          ((1, 1, 1), (-1, -1, -1))):
-            f = _manual_frame(vra, 16, 8, row0, (0, 0.25, 0), (0, 0, 0.25), org)
-            assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, _oracle(ora, f, scene, "dense"),
-                                f"requeue degenerate {row0} {org}")
-        # raytrace frames take the tile kernel of the raytrace instantiation, as before
-        pos, view = vra.orbit_camera(6, 16, 0.7)
-        f = vra.frame_from_camera(view, pos, hi, lo, 64, 40, raytrace=True)
-        assert_planes_equal({p: v[0] for p, v in gpu.render(f).items()}, ora.render_frame(f, target=scene.target), "requeue raytrace")
-        gpu.close()
-    monkeypatch.setenv("VOLLY_REQUEUE", "0")
-    gpu = vra.GpuScene.upload_dense(teapot64.target, teapot64.low)
-    assert gpu.info(8) == 0
-    gpu.close()
-
-
-def test_pt_end_plane_on_every_kernel(vra, ora, teapot64, monkeypatch):
+def test_pt_end_plane(vra, ora, teapot64):
     """The optional sixth plane, RaycastReport::ptEnd (main.cpp:81-86): three floats per ray, hits
-    and misses, for dense and octree targets, beam / naive / raytrace frames, through the tile
-    kernel, the refill kernel and the budgeted rounds; alone and together with the other planes;
-    into pageable and into pinned memory."""
+    and misses, for dense and octree targets, beam / naive / raytrace frames; alone and together
+    with the other planes; into pageable and into pinned memory.  (The experimental frame kernels
+    of the `experimental` variant build: tests/test_gpu_variants.py.)"""
     ALL = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth", "pt_end")
     hi, lo = _sizes(teapot64)
     frames = list(vra.orbit_frames((1, 9), 16, hi, lo, 101, 67, radius=0.9)) + list(vra.orbit_frames((4,), 16, hi, lo, 101, 67, naive=True))
-    for env in ({}, {"VOLLY_REFILL": "1"}, {"VOLLY_REQUEUE": "1", "VOLLY_REQUEUE_BUDGET": "9"}):
-        for k in ("VOLLY_REFILL", "VOLLY_REQUEUE", "VOLLY_REQUEUE_BUDGET"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        for kind in ("dense", "svo"):
-            gpu = _upload(vra, teapot64, kind)
-            got = gpu.render(frames, planes=ALL)
-            only = gpu.render(frames, planes=("pt_end",))
-            for i, f in enumerate(frames):
-                want = (ora.render_frame(f, low=teapot64.low, target=teapot64.target, planes=ALL) if kind == "dense"
-                        else ora.render_frame(f, low=teapot64.low, svo=teapot64.svo, planes=ALL))
-                assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"pt_end {kind} {env} frame {i}")
-                assert np.array_equal(only["pt_end"][i].view(np.uint32), want["pt_end"].view(np.uint32))
-                assert np.isfinite(want["pt_end"]).all()
-            if kind == "dense":
-                pos, view = vra.orbit_camera(6, 16, 0.7)
-                f = vra.frame_from_camera(view, pos, hi, lo, 64, 40, raytrace=True)
-                assert_planes_equal({p: v[0] for p, v in gpu.render(f, planes=ALL).items()},
-                                    ora.render_frame(f, target=teapot64.target, planes=ALL), f"pt_end raytrace {env}")
-            gpu.close()
-    for k in ("VOLLY_REFILL", "VOLLY_REQUEUE", "VOLLY_REQUEUE_BUDGET"):
-        monkeypatch.delenv(k, raising=False)
+    for kind in ("dense", "svo"):
+        gpu = _upload(vra, teapot64, kind)
+        got = gpu.render(frames, planes=ALL)
+        only = gpu.render(frames, planes=("pt_end",))
+        for i, f in enumerate(frames):
+            want = (ora.render_frame(f, low=teapot64.low, target=teapot64.target, planes=ALL) if kind == "dense"
+                    else ora.render_frame(f, low=teapot64.low, svo=teapot64.svo, planes=ALL))
+            assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"pt_end {kind} frame {i}")
+            assert np.array_equal(only["pt_end"][i].view(np.uint32), want["pt_end"].view(np.uint32))
+            assert np.isfinite(want["pt_end"]).all()
+        if kind == "dense":
+            pos, view = vra.orbit_camera(6, 16, 0.7)
+            f = vra.frame_from_camera(view, pos, hi, lo, 64, 40, raytrace=True)
+            assert_planes_equal({p: v[0] for p, v in gpu.render(f, planes=ALL).items()},
+                                ora.render_frame(f, target=teapot64.target, planes=ALL), "pt_end raytrace")
+        gpu.close()
     gpu = _upload(vra, teapot64, "svo")
     pin = vra.gpu.PinnedArray((len(frames), 67, 101, 3), np.float32)
     pin_rgba = vra.gpu.PinnedArray((len(frames), 67, 101), np.uint32)

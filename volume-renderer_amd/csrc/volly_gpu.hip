@@ -1,8 +1,16 @@
 // volly_gpu.hip -- C-ABI of the MI355X traversal path (include/volly_gpu.h).
 // Built for gfx950 only, with -ffp-contract=off (see volly_kernels.h).
 #include "volly_internal.h"
+// VK_EXPERIMENTAL=1 (the `experimental` build of `make variants`, never the shipped library) adds the
+// two frame kernels round 1 measured and did not adopt: ray refill (VOLLY_REFILL=1) and budgeted
+// rounds with parked rays (VOLLY_REQUEUE=1); tests/test_gpu_variants.py keeps them bit-exact.
+#ifndef VK_EXPERIMENTAL
+#define VK_EXPERIMENTAL 0
+#endif
+#if VK_EXPERIMENTAL
 #include "volly_refill.h"
 #include "volly_requeue.h"
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -180,6 +188,10 @@ static bool host_grid_is_regular(const vk::DenseDev &g)
 // at 25 % lane packing: 5.3 ms against 4.6 ms.  Off unless VOLLY_REFILL=1.
 void choose_frame_kernel(volly_gpu_scene *s)
 {
+#if !VK_EXPERIMENTAL
+    s->refill = s->requeue = false;                      // the shipped library has one dense and one octree frame kernel
+    return;
+#endif
     bool ok = !s->is_svo && host_grid_is_regular(s->target) && (!s->has_low || host_grid_is_regular(s->low));
     bool want = false;
     if (const char *e = std::getenv("VOLLY_REFILL")) want = ok && std::atoi(e) != 0;
@@ -245,14 +257,6 @@ int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, in
     return VOLLY_OK;
 }
 
-// VOLLY_PROBE_LDS=<bytes>: dynamic LDS per workgroup of the octree frame kernel, which it does not
-// use -- a measurement knob that lowers the number of resident wavefronts (160 KB per CU)
-size_t occupancy_probe_lds()
-{
-    static const size_t n = [] { const char *e = std::getenv("VOLLY_PROBE_LDS"); return e ? (size_t)std::atol(e) : (size_t)0; }();
-    return n;
-}
-
 size_t checkpoint_floats(const volly_frame_desc &f, int n)
 {
     return (size_t)n * (size_t)((f.tile_w + vk::kCkpt - 1) / vk::kCkpt) * (size_t)f.tile_h * 6;
@@ -310,9 +314,10 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         s->events.emplace_back(e0, e1);
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    dim3 grid((unsigned)((tw + vk::kBlockW * vk::kTilesPerWave - 1) / (vk::kBlockW * vk::kTilesPerWave)), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
+    dim3 grid((unsigned)((tw + vk::kBlockW - 1) / vk::kBlockW), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
     bool any_raytrace = false;
     for (int i = 0; i < n; ++i) any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
+#if VK_EXPERIMENTAL
     if (s->requeue && !any_raytrace && !no_alloc) {
         const size_t n_px = (size_t)n * tw * th;
         if (n_px >= (1ull << 32)) return fail(VOLLY_E_ARG, "render: more than 2^32 pixels per launch");
@@ -349,8 +354,10 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         const unsigned waves = (tiles + vk::kRaysPerWave / 64 - 1) / (vk::kRaysPerWave / 64);
         hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
                            s->low, d_frames, d_ckpt, o);
-    } else if (s->is_svo)
-        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), occupancy_probe_lds(), stream, s->target, s->svo, s->low, d_frames,
+    } else
+#endif
+    if (s->is_svo)
+        hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
                            d_ckpt, o);
     else if (any_raytrace)
         hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low,
@@ -678,6 +685,13 @@ int volly_gpu_read_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count
     return VOLLY_OK;
 }
 
+// which DDA loop trace_dense takes for a grid (volly_kernels.h), for wavefronts whose 64 rays are all regular
+static int dda_loop_of(const vk::DenseDev &g)
+{
+    if (!host_grid_is_regular(g)) return 3;               // trace_dense_checked
+    return g.use_regions ? 1 : 2;                         // trace_dense_regular_asm : trace_dense_bricks_asm
+}
+
 int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
 {
     if (!s) return -1;
@@ -696,6 +710,8 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 11: return s->svo.nodes ? (int64_t)s->n_leaves : 0;
     case 12: return s->svo.nodes ? s->svo.depth : 0;
     case 13: return s->target.vox != nullptr;
+    case 14: return s->is_svo ? 0 : dda_loop_of(s->target);
+    case 15: return s->has_low ? dda_loop_of(s->low) : 0;
     default: return -1;
     }
 }

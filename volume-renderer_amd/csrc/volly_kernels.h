@@ -28,12 +28,8 @@
 // process (profiles/ab_bench.py, Makefile target `variants`):
 //   VK_FAST_DDA=0     always use the fully checked DDA loop
 //   VK_OCC_LEVELS=1   one occupancy level (4^3 bricks) instead of two (bricks + 16^3 regions)
-//   VK_SVO_TABLE=0    locate octree cells by walking down from the root (top levels in LDS)
-//                     instead of starting at the direct-index table of the upper levels
-//   VK_AOS_SAMPLE=1   sample the reference's 8-byte voxels at every step (no occupancy bricks)
-//   VK_LINEAR_TILE=1  a wavefront covers 64x1 pixels instead of 8x8
-//   VK_LDS_TOP=0      do not stage the top of the octree in LDS
-//   VK_XCD_REMAP=1    give each XCD (blockIdx % 8) one contiguous range of pixel blocks
+//   VK_SVO_TABLE=0    locate octree cells by walking down from the root instead of starting at
+//                     the direct-index table of the upper levels
 //   VK_CKPT_STRIDE=4  a direction checkpoint every 4 pixels instead of 8 (at most 3 instead of 7
 //                     serial adds per lane and component, twice the checkpoint traffic: measured
 //                     1.4 % slower on config 2, 4 % on config 1)
@@ -44,15 +40,14 @@
 //   VK_ASM_BRICKS=0   the compiled loop for grids without the region level
 //   VK_SIGN_BFI=0     sign(d) * eps by compares, conversion and multiply also for regular wavefronts
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
-//   VK_TILES_PER_WAVE=K  a wavefront renders K tiles one after the other and asks for the next
-//                     tile's checkpoint early (measured 15-35 % slower for K = 2, 4, 8)
 //   VK_PROBE_WAVES=N  measurement only: N resident wavefronts per SIMD (register padding)
 //   VK_WAVE_BLOCK=N   N wavefronts (N tiles side by side) per workgroup, each storing its tile
 //                     straight from registers: no LDS, no barrier, 1/N of the workgroup dispatches
-//   VK_WAVE_BLOCK=0   four wavefronts (a 32x8 pixel block) per workgroup with the output rows
-//                     staged through LDS into 128-byte stores, instead of one wavefront per
-//                     workgroup storing its 8x8 tile straight from registers (no barrier at
-//                     which finished waves wait for the slowest of the block)
+// Designs that were measured and rejected in round 1 -- sampling the 8-byte voxels at every step,
+// a 32x2 wavefront tile, output rows staged through LDS, an XCD-contiguous block order, several
+// tiles per wavefront, the top of the octree in LDS, the ray-refill and parked-ray frame kernels
+// -- are no longer in this file: DESIGN.md section 5 has their numbers, profiles/r01_ab/ the logs,
+// the history (commit cfca876) the code.
 #ifndef VK_FAST_DDA
 #define VK_FAST_DDA 1
 #endif
@@ -60,28 +55,13 @@
 #define VK_OCC_LEVELS 2             // 1: bricks only; 2: bricks + one word per 4x4x4 bricks
 #endif
 #ifndef VK_SVO_TABLE
-#define VK_SVO_TABLE 1              // 0: walk down from the root at every iteration (top levels from LDS)
-#endif
-#ifndef VK_AOS_SAMPLE
-#define VK_AOS_SAMPLE 0
-#endif
-#ifndef VK_LINEAR_TILE
-#define VK_LINEAR_TILE 0
-#endif
-#ifndef VK_LDS_TOP
-#define VK_LDS_TOP 1
-#endif
-#ifndef VK_XCD_REMAP
-#define VK_XCD_REMAP 0
+#define VK_SVO_TABLE 1              // 0: walk down from the root at every iteration
 #endif
 #ifndef VK_WAVE_BLOCK
 #define VK_WAVE_BLOCK 1
 #endif
 #ifndef VK_SHORT_DIV
 #define VK_SHORT_DIV 1
-#endif
-#ifndef VK_TILES_PER_WAVE
-#define VK_TILES_PER_WAVE 1
 #endif
 #ifndef VK_ASM_QUIET
 #define VK_ASM_QUIET 1
@@ -105,23 +85,21 @@
 #define VK_CKPT_STRIDE 8
 #endif
 
-static_assert(!((VK_LINEAR_TILE != 0) && (VK_WAVE_BLOCK != 0)), "the 32x2 wavefront tile needs the 32x8 workgroup (VK_WAVE_BLOCK=0)");
+static_assert(VK_WAVE_BLOCK >= 1, "wavefronts per workgroup");
 
 namespace vk {
 
 constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
 constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pixels of a row (at most kCkpt - 1 adds per lane)
-constexpr int kBlockW = VK_WAVE_BLOCK ? 8 * VK_WAVE_BLOCK : 32;   // workgroup covers VK_WAVE_BLOCK tiles of 8 x 8 pixels side by side
+constexpr int kBlockW = 8 * VK_WAVE_BLOCK;   // workgroup covers VK_WAVE_BLOCK tiles of 8 x 8 pixels side by side
 constexpr int kBlockH = 8;
-constexpr int kTilesPerWave = VK_WAVE_BLOCK ? VK_TILES_PER_WAVE : 1;   // tiles a wavefront renders one after the other (side by side in x)
 #ifdef VK_PROBE_WAVES            // measurement only: cap the resident wavefronts per SIMD through the register allocation
 #define VK_FRAME_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(VK_PROBE_WAVES, VK_PROBE_WAVES)))
 #else
 #define VK_FRAME_WAVES_ATTR
 #endif
 constexpr int kThreads = 256;
-constexpr int kFrameThreads = VK_WAVE_BLOCK ? 64 * VK_WAVE_BLOCK : 256;   // workgroup size of render_frames
-constexpr int kTopNodes = VK_LDS_TOP ? 585 : 1;   // octree levels 0..3 (1 + 8 + 64 + 512 nodes) staged in LDS
+constexpr int kFrameThreads = 64 * VK_WAVE_BLOCK;   // workgroup size of render_frames
 
 struct DenseDev {
     const uint64_t *occ;            // one word per 4x4x4 brick, bit = x&3 | (y&3)<<2 | (z&3)<<4
@@ -308,15 +286,6 @@ __device__ __forceinline__ Hit trace_dense_checked(const DenseDev &g, const Ray 
         if (h.steps >= g.cap) break;
         int x = (int)px, y = (int)py, z = (int)pz;       // truncation toward zero, like glm::ivec4(vec4)
         ++h.steps;
-#if VK_AOS_SAMPLE
-        (void)last_brick; (void)bits;
-        const uint32_t idx = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
-        if (((g.vox[idx].x >> 24) != 0) != SOLID) {      // VolumeStore::sample + rgba.a > 0 (== 0 when solid), main.cpp:137-147
-            h.index = idx;
-            h.payload = idx;
-            break;
-        }
-#else
         int brick = (x >> 2) + g.nbx * ((y >> 2) + g.nby * (z >> 2));
         if (brick != last_brick) {
             bits = g.occ[brick];
@@ -328,7 +297,6 @@ __device__ __forceinline__ Hit trace_dense_checked(const DenseDev &g, const Ray 
             h.payload = h.index;
             break;
         }
-#endif
         advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
     }
     return h;
@@ -785,7 +753,7 @@ __device__ __forceinline__ Hit trace_dense_bricks_asm(const DenseDev &g, const R
 
 __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
-#if VK_FAST_DDA && !VK_AOS_SAMPLE
+#if VK_FAST_DDA
     // one path per wavefront, so the two loops never run interleaved in a wave
     if (grid_is_regular(g) && __all(ray_is_regular(r))) {
         // the 16^3 region level is chosen per grid at upload (DenseDev::use_regions)
@@ -813,8 +781,8 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
 // flattened at upload into a direct-index table (build_svo_table): one load gives either
 // "empty cell of 2^k voxels" or the node that covers the 2^tshift cell, from which at most
 // tshift more levels remain.  A lane keeps the last table entry and its node in registers.
-// With VK_SVO_TABLE=0 the walk starts at the root with the top levels staged in LDS.
-__device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, const Ray &r, float ox, float oy, float oz)
+// With VK_SVO_TABLE=0 the walk starts at the root.
+__device__ __forceinline__ Hit trace_svo(const SvoDev &t, const Ray &r, float ox, float oy, float oz)
 {
     Hit h;
     enter_volume(r, ox, oy, oz, t.fres, t.fres, t.fres, h.cx, h.cy, h.cz);
@@ -822,7 +790,6 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
     h.index = VOLLY_MISS_INDEX;
     h.payload = VOLLY_MISS_INDEX;
 #if VK_SVO_TABLE
-    (void)top;
     uint32_t last_cell = 0xFFFFFFFFu, entry = 0;
     uint2 entry_node = make_uint2(0u, 0u);
 #endif
@@ -849,7 +816,7 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
             sh = (int)(entry & 31u);                      // empty cell of 2^sh voxels, above the table's level
         } else
 #else
-        uint2 n = top[0];
+        uint2 n = t.nodes[0];
         sh = t.depth - 1;
 #endif
         for (;;) {
@@ -863,11 +830,7 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const uint2 *top, cons
                 hit = true;
                 break;
             }
-#if VK_SVO_TABLE
             n = t.nodes[child];
-#else
-            n = (child < (uint32_t)kTopNodes) ? top[child] : t.nodes[child];
-#endif
             --sh;
         }
         if (hit) {
@@ -1059,11 +1022,11 @@ __device__ __forceinline__ Ckpt load_checkpoint(const float *__restrict__ ckpt, 
 // main.cpp:256-272 for one pixel, from its checkpoint
 template <bool SVO, bool RAYTRACE>
 __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const SvoDev &svo, const DenseDev &low, const volly_frame_desc &fd,
-                                                 const uint2 *top, const Ckpt &k, int xrel)
+                                                 const Ckpt &k, int xrel)
 {
     PixelOut o;
     float hx = k.v[0], hy = k.v[1], hz = k.v[2], lx = k.v[3], ly = k.v[4], lz = k.v[5];
-#if VK_ASM_EXTRA && VK_WAVE_BLOCK && !VK_LINEAR_TILE && VK_CKPT_STRIDE == 8
+#if VK_ASM_EXTRA && VK_CKPT_STRIDE == 8
     // main.cpp:282-283: lane l of an 8-pixel row segment is l & 7 serial adds past its checkpoint.
     // Which lanes still add in round i is known at compile time (every eighth lane drops out per
     // round), so the rounds run under constant exec masks: 7 x (2 scalar + 6 vector)
@@ -1140,7 +1103,7 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
         sx = fd.scale_lo_to_hi[0] * lo.cx; sy = fd.scale_lo_to_hi[1] * lo.cy; sz = fd.scale_lo_to_hi[2] * lo.cz;
     }
 
-    Hit hi = SVO ? trace_svo(svo, top, ray_hi, sx, sy, sz) : trace_dense(target, ray_hi, sx, sy, sz);
+    Hit hi = SVO ? trace_svo(svo, ray_hi, sx, sy, sz) : trace_dense(target, ray_hi, sx, sy, sz);
     o.shi = hi.steps;
     o.hit = hi.index;
     o.ex = hi.cx; o.ey = hi.cy; o.ez = hi.cz;
@@ -1161,96 +1124,26 @@ __global__ void __launch_bounds__(kFrameThreads) VK_FRAME_WAVES_ATTR
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
               const float *__restrict__ ckpt, OutDev out)
 {
-    __shared__ uint2 top[(SVO && !VK_SVO_TABLE) ? kTopNodes : 1];
-#if !VK_WAVE_BLOCK
-    __shared__ uint32_t stage[5][kBlockH][kBlockW];
-#endif
-
-    if (SVO && !VK_SVO_TABLE) {
-        const uint32_t n = svo.n_nodes < (uint32_t)kTopNodes ? svo.n_nodes : (uint32_t)kTopNodes;
-        for (uint32_t i = threadIdx.x; i < n; i += kFrameThreads) top[i] = svo.nodes[i];
-        __syncthreads();
-    }
-
     const int f = blockIdx.z;
     // uniform, read with scalar loads where it is used: a by-value copy keeps ~50 scalar registers
     // busy for the whole kernel, and measured 0.5-1 % slower (profiles/r01_ab/ab_tiles_per_wave_c2.log, "new" vs "base")
     const volly_frame_desc &fd = frames[f];
-#if VK_XCD_REMAP
-    // workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD): renumber
-    // them so that each XCD renders one contiguous range of pixel blocks of the frame
-    const unsigned nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned q = nblk / 8, rem = nblk % 8, xcd = lin % 8;
-    const unsigned id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + lin / 8;
-    const int bx = (int)(id % gridDim.x), by = (int)(id / gridDim.x);
-#else
-    const int bx = blockIdx.x, by = blockIdx.y;
-#endif
+    // a wavefront covers an 8x8 tile; workgroups stay in dispatch order (round-robin over the XCDs
+    // balances sky and object tiles; an XCD-contiguous order measured 12-60 % slower)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#if VK_LINEAR_TILE
-    const int px_in_block = threadIdx.x & 31;             // a wavefront covers 32x2 pixels (two row segments)
-    const int py_in_block = threadIdx.x >> 5;
-    (void)wave; (void)lane;
-#else
-    const int px_in_block = wave * kTile + (lane & 7);    // a wavefront covers an 8x8 tile
-    const int py_in_block = lane >> 3;
-#endif
-    const int yrel = by * kBlockH + py_in_block;
-
-#if VK_WAVE_BLOCK
-    // kTilesPerWave > 1 (a measured and rejected variant): a wavefront renders
-    // that many tiles side by side, one after the other, and asks for the next tile's checkpoint
-    // before it marches through the current one.
-    const int x_first = bx * (kBlockW * kTilesPerWave) + px_in_block;
-    Ckpt next{};
-    if (x_first < fd.tile_w && yrel < fd.tile_h) next = load_checkpoint(ckpt, fd, f, x_first, yrel);
-    #pragma unroll 1
-    for (int t = 0; t < kTilesPerWave; ++t) {
-        const int xrel = x_first + t * kBlockW;
-        if (xrel - px_in_block >= fd.tile_w) break;       // uniform: the tile lies right of the sub-rectangle
-        const bool active = (xrel < fd.tile_w) & (yrel < fd.tile_h);
-        const Ckpt cur = next;
-        if (kTilesPerWave > 1 && t + 1 < kTilesPerWave && xrel + kBlockW < fd.tile_w && yrel < fd.tile_h)
-            next = load_checkpoint(ckpt, fd, f, xrel + kBlockW, yrel);
-        if (active) {                                     // eight 32-byte row segments per store instruction
-            const PixelOut o = render_pixel<SVO, RAYTRACE>(target, svo, low, fd, top, cur, xrel);
-            const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
-            if (out.rgba8) out.rgba8[p] = o.rgba;
-            if (out.hit_index) out.hit_index[p] = o.hit;
-            if (out.steps_lo) out.steps_lo[p] = o.slo;
-            if (out.steps_hi) out.steps_hi[p] = o.shi;
-            if (out.depth) out.depth[p] = o.depth;
-            if (out.pt_end) { out.pt_end[3 * p] = o.ex; out.pt_end[3 * p + 1] = o.ey; out.pt_end[3 * p + 2] = o.ez; }
-        }
+    const int xrel = (int)blockIdx.x * kBlockW + wave * kTile + (lane & 7);
+    const int yrel = (int)blockIdx.y * kBlockH + (lane >> 3);
+    if ((xrel < fd.tile_w) & (yrel < fd.tile_h)) {       // eight 32-byte row segments per store instruction
+        const Ckpt k = load_checkpoint(ckpt, fd, f, xrel, yrel);
+        const PixelOut o = render_pixel<SVO, RAYTRACE>(target, svo, low, fd, k, xrel);
+        const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
+        if (out.rgba8) out.rgba8[p] = o.rgba;
+        if (out.hit_index) out.hit_index[p] = o.hit;
+        if (out.steps_lo) out.steps_lo[p] = o.slo;
+        if (out.steps_hi) out.steps_hi[p] = o.shi;
+        if (out.depth) out.depth[p] = o.depth;
+        if (out.pt_end) { out.pt_end[3 * p] = o.ex; out.pt_end[3 * p + 1] = o.ey; out.pt_end[3 * p + 2] = o.ez; }
     }
-#else
-    const int xrel = bx * kBlockW + px_in_block;
-    const bool active = (xrel < fd.tile_w) & (yrel < fd.tile_h);
-    PixelOut o;
-    if (active) o = render_pixel<SVO, RAYTRACE>(target, svo, low, fd, top, load_checkpoint(ckpt, fd, f, xrel, yrel), xrel);
-    // framebuffer writeback: through LDS so that every store instruction writes
-    // whole 128-byte row segments (main.cpp:269-271 writes data_stream[x + y*W])
-    if (active && out.pt_end) {
-        const size_t q = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
-        out.pt_end[3 * q] = o.ex; out.pt_end[3 * q + 1] = o.ey; out.pt_end[3 * q + 2] = o.ez;
-    }
-    stage[0][py_in_block][px_in_block] = o.rgba;
-    stage[1][py_in_block][px_in_block] = o.hit;
-    stage[2][py_in_block][px_in_block] = o.slo;
-    stage[3][py_in_block][px_in_block] = o.shi;
-    stage[4][py_in_block][px_in_block] = __float_as_uint(o.depth);
-    __syncthreads();
-    const int wx = threadIdx.x & 31, wy = threadIdx.x >> 5;
-    const int oxr = bx * kBlockW + wx, oyr = by * kBlockH + wy;
-    if (oxr < fd.tile_w && oyr < fd.tile_h) {
-        const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)oyr * (size_t)fd.tile_w + (size_t)oxr;
-        if (out.rgba8) out.rgba8[p] = stage[0][wy][wx];
-        if (out.hit_index) out.hit_index[p] = stage[1][wy][wx];
-        if (out.steps_lo) out.steps_lo[p] = stage[2][wy][wx];
-        if (out.steps_hi) out.steps_hi[p] = stage[3][wy][wx];
-        if (out.depth) out.depth[p] = __uint_as_float(stage[4][wy][wx]);
-    }
-#endif
 }
 
 // ---- scene preparation --------------------------------------------------------

@@ -165,6 +165,12 @@ class GpuScene:
     def info(self, what):
         return int(lib.volly_gpu_scene_info(self._h, what))
 
+    def dda_loops(self):
+        """Which traversal loops this scene's frames run (volly_gpu_scene_info 14 / 15)."""
+        names = {0: "none", 1: "asm-regions", 2: "asm-bricks", 3: "checked"}
+        target = "octree" if self.info(3) else names[self.info(14)]
+        return f"target {target}, low {names[self.info(15)]}"
+
     @property
     def size(self):
         return (self.info(0), self.info(1), self.info(2))
