@@ -237,6 +237,33 @@ def test_device_entry_point_and_timing(vra, ora, teapot64):
     gpu.close()
 
 
+def test_calls_on_alternating_streams_share_the_scratch_safely(vra, teapot128):
+    """A scene's scratch (frame descriptors, direction checkpoints) is shared by its calls.  Calls
+    queued back to back on two different streams, with different cameras and nothing waited for in
+    between, must each produce what the same call produces alone: the second stream is made to
+    wait for the first (volume_gpu_render_device's contract)."""
+    import torch
+    hi, lo = _sizes(teapot128)
+    gpu = vra.GpuScene.upload_svo(teapot128.svo, teapot128.low)
+    dev = torch.device("cuda:0")
+    batches = [vra.orbit_frames(range(8 * b, 8 * b + 8), 64, hi, lo, 640, 360, radius=1.0) for b in range(6)]
+    want = []
+    for fr in batches:                                     # one at a time, fully synchronised
+        t = torch.empty((8, 360, 640), dtype=torch.int32, device=dev)
+        gpu.render_device(fr, {"hit_index": t.data_ptr()}, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want.append(t)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for _ in range(5):
+        got = [torch.empty((8, 360, 640), dtype=torch.int32, device=dev) for _ in batches]
+        for i, fr in enumerate(batches):                   # no synchronisation between the calls
+            gpu.render_device(fr, {"hit_index": got[i].data_ptr()}, stream=streams[i % 2].cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(len(batches)):
+            assert torch.equal(got[i], want[i]), f"batch {i} rendered on stream {i % 2}"
+    gpu.close()
+
+
 def test_config2_dragon512_full_frame(vra, ora):
     """BASELINE config 2: dragon.off at 512^3, octree target, 1920x1080, three
     cameras; all five planes bit-exact against the oracle on the full frame."""

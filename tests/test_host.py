@@ -275,6 +275,17 @@ def test_scene_cache_round_trip_and_rejection(vra, tmp_path):
             vra.HostScene.load(bad)
     with pytest.raises(RuntimeError):
         vra.HostScene.load(tmp_path / "nope.volly")
+    # a header that asks for 4096^3 voxels (512 GiB) and 2^32 - 1 leaves over a few bytes of payload:
+    # refused on the file's size, before anything is allocated (the load returns at once)
+    import struct, time
+    magic = raw[:8]
+    hostile = magic + struct.pack("<II3i3iIIiiQ", 1, 3, 4096, 4096, 4096, 4096, 4096, 4096, 1, 0xFFFFFFFF, 12, 4096, 0) + b"\0" * 64
+    bad = tmp_path / "hostile"
+    bad.write_bytes(hostile)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="size does not match"):
+        vra.HostScene.load(bad)
+    assert time.time() - t0 < 1.0
 
 
 def test_host_mesh_view_is_what_the_rasteriser_sees(vra):

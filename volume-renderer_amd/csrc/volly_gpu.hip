@@ -150,6 +150,7 @@ void destroy(volly_gpu_scene *s)
     DeviceGuard g(s->device);
     (void)hipDeviceSynchronize();
     for (auto &e : s->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (s->scratch_event) (void)hipEventDestroy(s->scratch_event);
     for (void *p : s->owned) (void)hipFree(p);
     if (s->d_frames) (void)hipFree(s->d_frames);
     if (s->d_ckpt) (void)hipFree(s->d_ckpt);
@@ -276,6 +277,23 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     volly_frame_desc *d_frames = fixed_frames;
     float *d_ckpt = fixed_ckpt;
     if (!no_alloc) {
+        // The scene's scratch (descriptors, checkpoints) is reused by every call.  Calls on one stream
+        // are ordered by the stream; when the stream CHANGES, the new stream first waits for everything
+        // queued on the previous one, or its pre-pass would overwrite what the previous frame kernel
+        // is still reading.  Nothing is recorded on the common path (same stream every call).
+        if (s->scratch_in_use && s->scratch_stream != stream) {
+            bool ordered = false;
+            if (!s->scratch_event) (void)hipEventCreateWithFlags(&s->scratch_event, hipEventDisableTiming);
+            if (s->scratch_event && hipEventRecord(s->scratch_event, s->scratch_stream) == hipSuccess &&
+                hipStreamWaitEvent(stream, s->scratch_event, 0) == hipSuccess)
+                ordered = true;
+            if (!ordered) {                               // e.g. the previous stream no longer exists
+                (void)hipGetLastError();
+                HIP_TRY(hipDeviceSynchronize());
+            }
+        }
+        s->scratch_stream = stream;
+        s->scratch_in_use = true;
         if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, sizeof(volly_frame_desc) * kFrameChunk));
         if (need > s->ckpt_floats) {
             if (s->d_ckpt) { HIP_TRY(hipFree(s->d_ckpt)); s->d_ckpt = nullptr; s->ckpt_floats = 0; }

@@ -61,6 +61,9 @@ struct volly_gpu_scene {
     volly_frame_desc *d_frames = nullptr;
     float *d_ckpt = nullptr;
     size_t ckpt_floats = 0;
+    hipStream_t scratch_stream = nullptr;   // the stream the last call queued its use of the scratch on
+    hipEvent_t scratch_event = nullptr;     // orders a call on another stream behind it (render_chunk)
+    bool scratch_in_use = false;
     void *d_planes = nullptr;       // staging of the synchronous entry point
     size_t plane_bytes = 0;
     hipStream_t s_render = nullptr, s_copy = nullptr;   // pinned-output path: render and copy-back overlap

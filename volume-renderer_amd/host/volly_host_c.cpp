@@ -4,6 +4,7 @@
 #include "tricube.h"
 
 #include <cstdio>
+#include <sys/types.h>
 #include <memory>
 #include <string>
 #include <vector>
@@ -56,7 +57,7 @@ extern "C" {
 const char *volly_host_last_error(void) { return g_err.c_str(); }
 
 volly_host_scene *volly_host_scene_from_mesh(const char *path, int32_t res, int32_t flags, int32_t n_threads)
-{
+try {
     g_err.clear();
     if (!path || res < 8 || (res % 4) != 0) { g_err = "volly_host_scene_from_mesh: need a path and res >= 8, multiple of 4"; return nullptr; }
     std::string err;
@@ -72,10 +73,13 @@ volly_host_scene *volly_host_scene_from_mesh(const char *path, int32_t res, int3
     if (flags & VOLLY_SCENE_DENSE) s->target.reset(volumeFromVoxelMap(s->map.get(), res, 0));   // main.cpp:32
     if (flags & VOLLY_SCENE_SVO) s->svo = std::make_unique<SparseVoxelOctree>(s->map.get(), res);
     return s.release();
+} catch (const std::exception &e) {          // e.g. std::bad_alloc: must not leave an extern "C" function
+    g_err = std::string("volly_host_scene_from_mesh: ") + e.what();
+    return nullptr;
 }
 
 volly_host_mesh *volly_host_mesh_load(const char *path, int32_t n_normalize)
-{
+try {
     g_err.clear();
     if (!path || n_normalize < 0) { g_err = "volly_host_mesh_load: bad arguments"; return nullptr; }
     std::string err;
@@ -88,6 +92,9 @@ volly_host_mesh *volly_host_mesh_load(const char *path, int32_t n_normalize)
     auto m = std::make_unique<volly_host_mesh>();
     m->poly = std::move(poly);
     return m.release();
+} catch (const std::exception &e) {          // e.g. std::bad_alloc: must not leave an extern "C" function
+    g_err = std::string("volly_host_mesh_load: ") + e.what();
+    return nullptr;
 }
 
 int volly_host_mesh_view(const volly_host_mesh *m, volly_mesh_desc *out)
@@ -103,7 +110,7 @@ int volly_host_mesh_view(const volly_host_mesh *m, volly_mesh_desc *out)
 void volly_host_mesh_free(volly_host_mesh *m) { delete m; }
 
 volly_host_scene *volly_host_scene_sphere(int32_t res, const uint8_t fill[8], int32_t flags)
-{
+try {
     g_err.clear();
     if (res < 4 || !fill) { g_err = "volly_host_scene_sphere: bad arguments"; return nullptr; }
     auto s = std::make_unique<volly_host_scene>();
@@ -114,10 +121,13 @@ volly_host_scene *volly_host_scene_sphere(int32_t res, const uint8_t fill[8], in
     s->low.reset(reduce_any(s->target.get(), 4));
     if (flags & VOLLY_SCENE_SVO) s->svo = std::make_unique<SparseVoxelOctree>(s->target.get());
     return s.release();
+} catch (const std::exception &e) {          // e.g. std::bad_alloc: must not leave an extern "C" function
+    g_err = std::string("volly_host_scene_sphere: ") + e.what();
+    return nullptr;
 }
 
 volly_host_scene *volly_host_scene_from_dense(const volly_dense_desc *target, const volly_dense_desc *low, int32_t flags)
-{
+try {
     g_err.clear();
     if (!target || !target->voxels || target->sx < 1 || target->sy < 1 || target->sz < 1) {
         g_err = "volly_host_scene_from_dense: bad target";
@@ -128,6 +138,9 @@ volly_host_scene *volly_host_scene_from_dense(const volly_dense_desc *target, co
     if (low && low->voxels) s->low.reset(copy_grid(low));
     if (flags & VOLLY_SCENE_SVO) s->svo = std::make_unique<SparseVoxelOctree>(s->target.get());
     return s.release();
+} catch (const std::exception &e) {          // e.g. std::bad_alloc: must not leave an extern "C" function
+    g_err = std::string("volly_host_scene_from_dense: ") + e.what();
+    return nullptr;
 }
 
 int volly_host_scene_target(const volly_host_scene *s, volly_dense_desc *out)
@@ -239,6 +252,19 @@ volly_host_scene *volly_host_scene_load(const char *path)
         g_err = std::string("implausible header in ") + path;
         return nullptr;
     }
+    // the header sizes every allocation below: hold it against the file's real size first, so that a
+    // truncated or hostile file cannot ask for hundreds of gigabytes (4096^3 voxels, 2^32 leaves)
+    auto cells = [](const int32_t d[3]) { return (uint64_t)d[0] * (uint64_t)d[1] * (uint64_t)d[2]; };
+    uint64_t payload = cells(h.low) * sizeof(Voxel);
+    if (h.flags & VOLLY_SCENE_DENSE) payload += cells(h.target) * sizeof(Voxel);
+    if (h.flags & VOLLY_SCENE_SVO) payload += (uint64_t)h.n_nodes * sizeof(volly_svo_node) + (uint64_t)h.n_leaves * sizeof(Voxel);
+    long long file_size = -1;
+    if (fseeko(in.f, 0, SEEK_END) == 0) file_size = (long long)ftello(in.f);
+    if (file_size < 0 || fseeko(in.f, (off_t)sizeof h, SEEK_SET) != 0 || (uint64_t)file_size != sizeof h + payload) {
+        g_err = std::string("truncated or corrupted scene cache (size does not match its header): ") + path;
+        return nullptr;
+    }
+    try {
     auto s = std::make_unique<volly_host_scene>();
     uint64_t sum = 0xCBF29CE484222325ull;
     auto read = [&](void *p, size_t n) {
@@ -267,16 +293,23 @@ volly_host_scene *volly_host_scene_load(const char *path)
         return nullptr;
     }
     return s.release();
+    } catch (const std::exception &e) {                    // std::bad_alloc must not leave an extern "C" function
+        g_err = std::string("volly_host_scene_load: ") + e.what() + ": " + path;
+        return nullptr;
+    }
 }
 
 volly_host_lod_set *volly_host_lod_set_load(const char *path, int32_t sLowR, int32_t lowR, int32_t medR, int32_t highR)
-{
+try {
     g_err.clear();
     if (!path || sLowR < 1 || lowR < 1 || medR < 1) { g_err = "volly_host_lod_set_load: bad arguments"; return nullptr; }
     auto s = std::make_unique<volly_host_lod_set>();
     s->set = std::make_unique<Vol_LOD_Set>(path, 0, sLowR, lowR, medR, highR);
     if (!s->set->error.empty()) { g_err = s->set->error; return nullptr; }
     return s.release();
+} catch (const std::exception &e) {          // e.g. std::bad_alloc: must not leave an extern "C" function
+    g_err = std::string("volly_host_lod_set_load: ") + e.what();
+    return nullptr;
 }
 
 int volly_host_lod_set_grid(const volly_host_lod_set *s, int32_t which, volly_dense_desc *out)
