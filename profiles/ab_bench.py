@@ -3,7 +3,8 @@
 (cdna_hip_programming.md rule 24): N variants x M rounds, HIP-event kernel time of
 render_frames only, median and min per variant.
 
-    python profiles/ab_bench.py [--config 2] [--mode beam] [--rounds 7] name=path/to/lib.so ...
+    python profiles/ab_bench.py [--config 2] [--mode beam] [--rounds 7] name=path/to/lib.so[@ENV=value...] ...
+(@ENV=value: environment the library reads while the variant's scene is created, e.g. @VOLLY_EMPTY_CUBES=4)
 """
 import argparse, importlib.util, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,6 +52,9 @@ def main():
     gpus, sums = {}, {}
     for v in a.variants:
         name, path = v.split("=", 1)
+        path, *envs = path.split("@")
+        for e in envs:
+            os.environ[e.split("=", 1)[0]] = e.split("=", 1)[1]
         mod = load_variant(name, path)
         if scene is None:
             g = mod.GpuScene.noise(res, 1, 1 << 24)
@@ -58,6 +62,8 @@ def main():
             g = mod.GpuScene.upload_dense(scene.target, scene.low)
         else:
             g = mod.GpuScene.upload_svo(scene.svo, scene.low)
+        for e in envs:
+            os.environ.pop(e.split("=", 1)[0], None)
         g.render_device(frames[0], ptrs)
         torch.cuda.synchronize()
         sums[name] = tuple(int(planes[q].sum(dtype=torch.int64).item()) for q in ("hit_index", "steps_lo", "steps_hi", "rgba8"))

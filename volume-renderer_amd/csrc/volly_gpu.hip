@@ -135,6 +135,14 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
     uint32_t nonempty = 0;
     HIP_TRY(hipMemcpy(&nonempty, counter, 4, hipMemcpyDeviceToHost));
     d.occ2 = occ2;
+    uint4 *occ2x = nullptr;
+    if ((rc = dev_alloc(s, (void **)&occ2x, nr * 16))) return rc;
+    int max_level = 7;                                    // empty cubes of up to 128^3 voxels; VOLLY_EMPTY_CUBES=4 switches them off (A/B runs)
+    if (const char *e = std::getenv("VOLLY_EMPTY_CUBES")) max_level = std::min(std::max(std::atoi(e), 4), 7);
+    hipLaunchKernelGGL(vk::build_region_cubes, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, 0, occ2, d.nrx, d.nry, d.nrz, max_level, occ2x);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    d.occ2x = occ2x;
     // The region level pays when a fair share of the 16^3 regions is empty (surface scenes:
     // 20-55 % of the regions hold voxels in the bundled meshes, +9 % Mrays/s); in a noise
     // volume every region holds voxels and it is pure overhead (-7 %).  VOLLY_USE_REGIONS=0/1 overrides.
@@ -733,6 +741,19 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     default: return -1;
     }
 }
+
+#if VK_COUNT
+// measurement build only (make variants, `count`): event counters of the whole-traversal loop
+int volly_gpu_debug_counters(unsigned long long *out16, int reset)
+{
+    if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(vk::vk_counters), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long zero[16] = {};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(vk::vk_counters), zero, sizeof zero));
+    }
+    return VOLLY_OK;
+}
+#endif
 
 void volly_gpu_free(volly_gpu_scene *scene) { destroy(scene); }
 
