@@ -26,7 +26,7 @@ SRC = os.path.join(ROOT, "volume-renderer_amd", "csrc", "volly_gpu.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include")]
 OURS = (re.compile(r"^s_mov_b32 m0, 0$"), re.compile(r"^s_mov_b32 s\d+, m0$"), re.compile(r"^s_add_u32 m0, m0, 1$"),
-        re.compile(r"^s_cmp_ge_u32 m0, s\d+$"), re.compile(r"^s_add_u32 s\d+, m0, 1$"))
+        re.compile(r"^s_cmp_ge_u32 m0, s\d+$"), re.compile(r"^s_add_u32 s\d+, m0, \d+$"))
 LIVE = ("_ZN2vk13render_framesILb1ELb0EEE", "_ZN2vk13render_framesILb0ELb0EEE")
 MAX_VGPR, MAX_SGPR = 64, 96
 

@@ -64,6 +64,8 @@ def main():
         lvl = np.where(np.repeat(np.repeat(np.repeat(e, b, 0), b, 1), b, 2) & emp, L, lvl)
     print("empty regions by cube level", [int(((lvl == L) & emp).sum()) for L in range(4)])
     cube = dict(old=0, new=0)
+    KS = (4, 8, 16)
+    deepc = {k: dict(cov=0, tests=0, fails=0) for k in KS}
     blk = dict(covered=0, blocks=0, evals=0)
     rng = np.random.default_rng(1)
     tot = dict(steps=0, quiet=0, allE=0, deep4=0, deep2=0, lanes=0, live=0)
@@ -86,6 +88,8 @@ def main():
         prev_reg = np.full(cur.shape[:2], -1, np.int64); prev_brk = np.full(cur.shape[:2], -1, np.int64)
         octant = (d[..., 0] > 0).astype(np.int64) | ((d[..., 1] > 0).astype(np.int64) << 1) | ((d[..., 2] > 0).astype(np.int64) << 2)
         w_shift = np.full(cur.shape[:2], 4, np.int64); w_key = np.full(cur.shape[:2], -1, np.int64)
+        w_valid = np.zeros(cur.shape[:2], bool)
+        d_left = {k: np.zeros(cur.shape[0], np.int64) for k in KS}; d_try = {k: np.ones(cur.shape[0], bool) for k in KS}
         free_until = np.zeros(cur.shape[:2], np.int64)
         skip_left = np.zeros(cur.shape[0], np.int64)
         MINBLOCK = int(os.environ.get("MINBLOCK", "8"))
@@ -136,6 +140,24 @@ def main():
             w_shift = np.where(left, nl, w_shift)
             k_new = np.where(w_shift == 4, ckey(4), np.where(w_shift == 5, ckey(5), np.where(w_shift == 6, ckey(6), ckey(7))))
             w_key = np.where(left, k_new, w_key)
+            w_valid = np.where(left, E, w_valid)          # the watch is a cube only in an empty region
+            # unchecked blocks of K steps: all live lanes stay inside their watch cube for K more steps
+            sgn = np.where(d > 0, 1, -1)
+            for K_ in KS:
+                ok = w_valid.copy()
+                xs = (x + sgn[..., 0] * K_, y + sgn[..., 1] * K_, z + sgn[..., 2] * K_)
+                k_far = sum(((v >> w_shift) & 1023) << (10 * a) for a, v in enumerate(xs))
+                inb = (xs[0] >= 0) & (xs[0] < n) & (xs[1] >= 0) & (xs[1] < n) & (xs[2] >= 0) & (xs[2] < n)
+                ok &= inb & (k_far == w_key)
+                wave_ok = (ok | ~live).all(1) & wl
+                running = d_left[K_] > 0
+                attempt = ~running & wl & d_try[K_] & ~left.any(1)
+                deepc[K_]["tests"] += int(attempt.sum()); deepc[K_]["fails"] += int((attempt & ~wave_ok).sum())
+                startb = attempt & wave_ok
+                d_try[K_] = np.where(attempt, wave_ok, d_try[K_]) | left.any(1)
+                d_left[K_] = np.where(startb, K_, d_left[K_])
+                deepc[K_]["cov"] += int(((d_left[K_] > 0) & wl).sum())
+                d_left[K_] = np.maximum(d_left[K_] - 1, 0)
             # skip blocks: a lane entering a region learns for how many steps it is surely in empty space inside the grid
             changed = live & (reg_id != prev_reg)
             kk = K[octant, z >> 4, y >> 4, x >> 4]
@@ -158,6 +180,8 @@ def main():
     print(f"wave-steps {s}  all-quiet {tot['quiet']/s:.3f}  all-in-empty-regions {tot['allE']/s:.3f}  deep>=3 {tot['deep4']/s:.3f}  deep>=1 {tot['deep2']/s:.3f}  live lanes/step {tot['live']/s:.1f}")
     print(f"octant skip blocks (min {os.environ.get('MINBLOCK', '8')}) cover {blk['covered']/s:.3f} of the wave-steps in {blk['blocks']} blocks (mean {blk['covered']/max(1,blk['blocks']):.1f} steps), wave-min evaluations {blk['evals']/s:.3f} per wave-step")
     print(f"wave-steps with a region change: {cube['old']/s:.3f}; with adaptive empty cubes (32^3..128^3): {cube['new']/s:.3f}")
+    for K_ in KS:
+        print(f"unchecked blocks of {K_} steps inside the watch cubes cover {deepc[K_]['cov']/s:.3f} of the wave-steps; tests {deepc[K_]['tests']/s:.3f}, failed {deepc[K_]['fails']/s:.3f} per wave-step")
     print(f"greedy 4-blocks cover {greedy4/s:.3f} of the wave-steps; deep tests {tests4/s:.3f} per wave-step, failed {fails4/s:.3f} per wave-step")
 
 main()

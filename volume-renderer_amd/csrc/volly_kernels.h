@@ -640,6 +640,52 @@ __device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const 
 // from the grid's sizes alone (whole 16^3 regions: sy and sx are multiples of 16, so
 // ((z>>4)*sy + (y&~15)) * sx is 256 * the region row index), which keeps the statement within
 // the 30 operands an asm statement may take.
+#ifndef VK_RUN_AHEAD
+#define VK_RUN_AHEAD 4               // steps the whole-traversal loop takes without looking when every lane is deep inside its empty cube (0: never)
+#endif
+#define VK_STR2(x) #x
+#define VK_STR(x) VK_STR2(x)
+// advance_unit (main.cpp:149-153) on the sample point in v47-v49, for the loops below
+#define VK_ADVANCE_UNIT \
+        "v_floor_f32 v53, v47\n\t" \
+        "v_floor_f32 v54, v48\n\t" \
+        "v_floor_f32 v55, v49\n\t" \
+        "v_add_f32 v53, v53, %[hx]\n\t" \
+        "v_add_f32 v54, v54, %[hy]\n\t" \
+        "v_add_f32 v55, v55, %[hz]\n\t" \
+        "v_sub_f32 v53, v53, %[cx]\n\t" \
+        "v_sub_f32 v54, v54, %[cy]\n\t" \
+        "v_sub_f32 v55, v55, %[cz]\n\t" \
+        "v_mul_f32 v53, v53, %[ix]\n\t" \
+        "v_mul_f32 v54, v54, %[iy]\n\t" \
+        "v_mul_f32 v55, v55, %[iz]\n\t" \
+        "v_min3_f32 v53, v53, v54, v55\n\t" \
+        "v_mul_f32 v54, v53, %[dx]\n\t" \
+        "v_mul_f32 v55, v53, %[dy]\n\t" \
+        "v_mul_f32 v53, v53, %[dz]\n\t" \
+        "v_add_f32 %[cx], v54, %[cx]\n\t" \
+        "v_add_f32 %[cy], v55, %[cy]\n\t" \
+        "v_add_f32 %[cz], v53, %[cz]\n\t"
+// one more step without cell, key or test: the sample point, then the advance
+#define VK_BLIND_STEP \
+        "s_add_u32 m0, m0, 1\n\t" \
+        "v_add_f32 v47, %[cx], %[ex]\n\t" \
+        "v_add_f32 v48, %[cy], %[ey]\n\t" \
+        "v_add_f32 v49, %[cz], %[ez]\n\t" \
+        VK_ADVANCE_UNIT
+#if VK_RUN_AHEAD == 2
+#define VK_RUN_AHEAD_MORE VK_BLIND_STEP
+#elif VK_RUN_AHEAD == 3
+#define VK_RUN_AHEAD_MORE VK_BLIND_STEP VK_BLIND_STEP
+#elif VK_RUN_AHEAD == 4
+#define VK_RUN_AHEAD_MORE VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP
+#elif VK_RUN_AHEAD == 6
+#define VK_RUN_AHEAD_MORE VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP
+#elif VK_RUN_AHEAD == 8
+#define VK_RUN_AHEAD_MORE VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP VK_BLIND_STEP
+#else
+#define VK_RUN_AHEAD_MORE
+#endif
 #ifndef VK_COUNT
 #define VK_COUNT 0                   // 1: measurement build, the whole-traversal loop counts its events
 #endif
@@ -664,11 +710,17 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
     uint32_t steps = 0xFFFFFFFFu;                         // still live
     uint32_t hitc = 0xFFFFFFFFu;                          // packed cell of the hit
     uint64_t mask_e, mask_a, mask_b, mask_c;
-    uint32_t tmp;
+    uint32_t tmp, tr;
+    // the packed-cell offset of VK_RUN_AHEAD cells along the ray's octant (fields wrap: a field that leaves
+    // [0, 1024) changes its own high bits, so the masked compare fails, which is the safe answer)
+    const uint32_t k_ahead = (uint32_t)VK_RUN_AHEAD;
+    const uint32_t ahead = (r.dx < 0.0f ? 0u - k_ahead : k_ahead) + ((r.dy < 0.0f ? 0u - k_ahead : k_ahead) << 10) +
+                           ((r.dz < 0.0f ? 0u - k_ahead : k_ahead) << 20);
     asm volatile(
         "s_mov_b64 %[se], exec\n\t"
         VK_CNT("s_mov_b32 s88, 0\n\ts_mov_b32 s89, 0\n\ts_mov_b32 s90, 0\n\ts_mov_b32 s91, 0\n\ts_mov_b32 s92, 0\n\ts_mov_b32 s93, 0\n\ts_mov_b32 s94, 0\n\ts_mov_b32 s95, 0\n\t")
         "s_mov_b32 m0, 0\n\t"
+        "s_mov_b32 %[tr], 1\n\t"
         "v_mov_b32 v57, -1\n\t"                       // no region yet
         "v_mov_b32 v58, 0\n\t"
         "v_mov_b32 v59, 0\n\t"
@@ -690,27 +742,30 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         "v_cmp_ne_u32 vcc, v53, v62\n\t"
         "s_cbranch_vccnz 3f\n\t"
         "s_cmp_ge_u32 m0, %[cap]\n\t"
-        "s_cbranch_scc1 9f\n"
+        "s_cbranch_scc1 9f\n\t"
+#if VK_RUN_AHEAD
+        // ---- every live lane is quiet.  If each one's cell VK_RUN_AHEAD steps further along its ray (a step moves
+        // every coordinate by at most one cell, always in the ray's direction) still lies in its empty cube, the
+        // next VK_RUN_AHEAD steps can hit nothing and cannot leave the grid: they run without cell, key or test.
+        // `tr` remembers whether the last such test passed; any attention step re-arms it.
+        "s_cmp_eq_u32 %[tr], 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "v_add_u32 v53, v56, %[ahead]\n\t"
+        "v_and_b32 v53, v63, v53\n\t"
+        "v_cmp_ne_u32 vcc, v53, v62\n\t"
+        "s_cbranch_vccnz 8f\n\t"
+        "s_add_u32 %[tmp], m0, " VK_STR(VK_RUN_AHEAD) "\n\t"
+        "s_cmp_gt_u32 %[tmp], %[cap]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        VK_ADVANCE_UNIT
+        VK_RUN_AHEAD_MORE
+        "s_add_u32 m0, m0, 1\n\t"
+        "s_branch 1b\n"
+        "8:\n\t"
+        "s_mov_b32 %[tr], 0\n"
+#endif
         "2:\n\t"                                      // ---- advance_unit (main.cpp:149-153), every live lane
-        "v_floor_f32 v53, v47\n\t"
-        "v_floor_f32 v54, v48\n\t"
-        "v_floor_f32 v55, v49\n\t"
-        "v_add_f32 v53, v53, %[hx]\n\t"
-        "v_add_f32 v54, v54, %[hy]\n\t"
-        "v_add_f32 v55, v55, %[hz]\n\t"
-        "v_sub_f32 v53, v53, %[cx]\n\t"
-        "v_sub_f32 v54, v54, %[cy]\n\t"
-        "v_sub_f32 v55, v55, %[cz]\n\t"
-        "v_mul_f32 v53, v53, %[ix]\n\t"
-        "v_mul_f32 v54, v54, %[iy]\n\t"
-        "v_mul_f32 v55, v55, %[iz]\n\t"
-        "v_min3_f32 v53, v53, v54, v55\n\t"
-        "v_mul_f32 v54, v53, %[dx]\n\t"
-        "v_mul_f32 v55, v53, %[dy]\n\t"
-        "v_mul_f32 v53, v53, %[dz]\n\t"
-        "v_add_f32 %[cx], v54, %[cx]\n\t"
-        "v_add_f32 %[cy], v55, %[cy]\n\t"
-        "v_add_f32 %[cz], v53, %[cz]\n\t"
+        VK_ADVANCE_UNIT
         "s_add_u32 m0, m0, 1\n\t"
         "s_branch 1b\n"
         "3:\n\t"                                      // ---- vcc = the lanes that are not quiet
@@ -808,15 +863,16 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         "v_mov_b32 %[hitc], v56\n\t"
         "s_andn2_b64 %[sa], %[sa], vcc\n"
         "7:\n\t"
+        "s_mov_b32 %[tr], 1\n\t"
         "s_mov_b64 exec, %[sa]\n\t"
         "s_cbranch_execnz 2b\n"                       // the step itself, for the lanes still live
         "9:\n\t"
         "s_mov_b64 exec, %[se]"
         : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [steps] "+v"(steps), [hitc] "+v"(hitc),
-          [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sb] "=&s"(mask_b), [sc] "=&s"(mask_c), [tmp] "=&s"(tmp)
+          [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sb] "=&s"(mask_b), [sc] "=&s"(mask_c), [tmp] "=&s"(tmp), [tr] "=&s"(tr)
         : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
           [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-          [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [occ2] "s"(occ2), [occ] "s"(occ)
+          [ahead] "v"(ahead), [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [occ2] "s"(occ2), [occ] "s"(occ)
         : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
           "v60", "v61", "v62", "v63"
 #if VK_COUNT
