@@ -70,6 +70,9 @@
 #ifndef VK_ASM_WHOLE
 #define VK_ASM_WHOLE 1               // 0: the region loop that leaves for compiled code at bricks with voxels and at the grid's faces
 #endif
+#ifndef VK_BRICK_BLOCKS
+#define VK_BRICK_BLOCKS 0           // 1: the bricks-only loop reads a copy of the bricks laid out 2x2x2 per 64-byte line (measured, not adopted)
+#endif
 #ifndef VK_ASM_EXTRA
 #define VK_ASM_EXTRA 1
 #endif
@@ -108,6 +111,7 @@ constexpr int kFrameThreads = 64 * VK_WAVE_BLOCK;   // workgroup size of render_
 struct DenseDev {
     const uint64_t *occ;            // one word per 4x4x4 brick, bit = x&3 | (y&3)<<2 | (z&3)<<4
     const uint64_t *occ2;           // one word per 4x4x4 bricks (16^3 voxels): bit set iff that brick has a voxel
+    const uint64_t *occb;           // VK_BRICK_BLOCKS=1 (measurement build) only: the bricks again, 2x2x2 of them per 64-byte line
     const uint4 *occ2x;             // per region {occ2 word, key mask of the largest empty aligned cube (16^3 .. 128^3 voxels) around it, 0}:
                                     // what the whole-traversal loop loads on a region change (build_region_cubes)
     const uint2 *vox;               // the reference's 8-byte voxels, x + sx*(y + sy*z)
@@ -1036,6 +1040,138 @@ __device__ __forceinline__ Hit trace_dense_bricks_asm(const DenseDev &g, const R
     return h;
 }
 
+// trace_dense_bricks_asm with nothing left to compiled code (VK_ASM_WHOLE): in a grid without the region
+// level (the noise volume) ray lengths scatter, so nearly every lane of a wavefront ends at a step of its
+// own, and each such end used to send the whole wavefront through the per-lane C++ block.  Here a lane
+// that leaves the grid or samples a voxel records its result under an exec mask and drops out of the
+// loop's live mask.  Fixed registers: v47-v55 temporaries, v56 packed cell, v46 brick key, v44-v45 brick word.
+__device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
+    const uint32_t cap = g.cap;
+    const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz;
+#if VK_BRICK_BLOCKS
+    const uint64_t *occ = g.occb;
+#else
+    const uint64_t *occ = g.occ;
+#endif
+    uint32_t steps = 0xFFFFFFFFu;                         // still live
+    uint32_t hitc = 0xFFFFFFFFu;                          // packed cell of the hit
+    uint64_t mask_e, mask_a, mask_c;
+    uint32_t tmp;
+    asm volatile(
+        "s_mov_b64 %[se], exec\n\t"
+        "s_mov_b32 m0, 0\n\t"
+        "v_mov_b32 v46, -1\n\t"                       // no brick yet
+        "v_mov_b32 v44, 0\n\t"
+        "v_mov_b32 v45, 0\n"
+        "1:\n\t"                                      // ---- sample point, cell, brick key (exec = live lanes)
+        "v_add_f32 v47, %[cx], %[ex]\n\t"
+        "v_add_f32 v48, %[cy], %[ey]\n\t"
+        "v_add_f32 v49, %[cz], %[ez]\n\t"
+        "v_cvt_i32_f32 v50, v47\n\t"
+        "v_cvt_i32_f32 v51, v48\n\t"
+        "v_cvt_i32_f32 v52, v49\n\t"
+        "v_lshl_or_b32 v56, v51, 10, v50\n\t"
+        "v_lshl_or_b32 v56, v52, 20, v56\n\t"
+        "s_cmp_ge_u32 m0, %[cap]\n\t"
+        "s_cbranch_scc1 9f\n\t"
+        "v_and_b32 v53, 0xffcff3fc, v56\n\t"
+        "v_cmp_ne_u32 vcc, v53, v46\n\t"
+        "s_cbranch_vccz 4f\n\t"
+        "s_mov_b64 %[sa], exec\n\t"                   // sa: the live lanes
+        "s_mov_b64 exec, vcc\n\t"                     // ---- lanes in a new brick
+        "v_cmp_gt_u32 vcc, %[sx], v50\n\t"
+        "v_cmp_gt_u32 %[sc], %[sy], v51\n\t"
+        "s_and_b64 vcc, vcc, %[sc]\n\t"
+        "v_cmp_gt_u32 %[sc], %[sz], v52\n\t"
+        "s_and_b64 vcc, vcc, %[sc]\n\t"               // vcc: new brick inside the grid
+        "s_andn2_b64 %[sc], exec, vcc\n\t"            // sc: outside
+        "s_cbranch_scc0 3f\n\t"
+        "s_mov_b64 exec, %[sc]\n\t"                   // ---- lanes leaving the grid: main.cpp:126-135
+        "s_mov_b32 %[tmp], m0\n\t"
+        "v_mov_b32 %[steps], %[tmp]\n\t"
+        "s_andn2_b64 %[sa], %[sa], %[sc]\n"
+        "3:\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "s_cbranch_execz 5f\n\t"
+#if VK_BRICK_BLOCKS
+        // measured alternative layout: a 64-byte line holds a 2x2x2 block of bricks (8^3 voxels), lines x fastest:
+        // byte offset = 64 * (x>>3 + nlx * (y>>3 + nly * (z>>3))) + 8 * ((x>>2)&1 | (y>>2)&1 << 1 | (z>>2)&1 << 2)
+        "v_lshrrev_b32 v54, 3, v52\n\t"
+        "v_and_b32 v55, 0xfffffff8, v51\n\t"
+        "v_mad_u32_u24 v54, v54, %[sy], v55\n\t"      // 8 * (y>>3 + nly * (z>>3))
+        "v_mul_u32_u24 v54, v54, %[sx]\n\t"           // 64 * nlx * (...)
+        "v_lshrrev_b32 v55, 3, v50\n\t"
+        "v_lshl_add_u32 v54, v55, 6, v54\n\t"
+        "v_lshrrev_b32 v55, 2, v56\n\t"               // bits 0, 10, 20 = bit 2 of x, y, z
+        "v_and_b32 v55, 0x100401, v55\n\t"
+        "v_mul_u32_u24 v55, 0x40201, v55\n\t"         // gathered at bits 20..22
+        "v_bfe_u32 v55, v55, 20, 3\n\t"
+        "v_lshl_add_u32 v54, v55, 3, v54\n\t"
+#else
+        "v_lshrrev_b32 v54, 2, v52\n\t"               // byte offset of the brick word: 8 * (x>>2 + nbx * (y>>2 + nby * (z>>2)))
+        "v_and_b32 v55, 0xfffffffc, v51\n\t"
+        "v_mad_u32_u24 v54, v54, %[sy], v55\n\t"      // 4 * (y>>2 + nby * (z>>2))
+        "v_mul_u32_u24 v54, v54, %[sx]\n\t"           // 16 * nbx * (...)
+        "v_lshrrev_b32 v54, 1, v54\n\t"
+        "v_lshrrev_b32 v55, 2, v50\n\t"
+        "v_lshl_add_u32 v54, v55, 3, v54\n\t"
+#endif
+        "global_load_dwordx2 v[44:45], v54, %[occ]\n\t"
+        "v_mov_b32 v46, v53\n\t"
+        "s_waitcnt vmcnt(0)\n"
+        "5:\n\t"
+        "s_mov_b64 exec, %[sa]\n\t"
+        "s_cbranch_execz 9f\n"
+        "4:\n\t"                                      // ---- lanes whose brick holds voxels: the cell's bit
+        "v_cmp_ne_u64 vcc, 0, v[44:45]\n\t"
+        "s_cbranch_vccz 6f\n\t"
+        "s_mov_b64 %[sa], exec\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_and_b32 v54, 0x300c03, v56\n\t"
+        "v_mul_u32_u24 v54, 0x40404, v54\n\t"
+        "v_bfe_u32 v54, v54, 18, 6\n\t"
+        "v_lshrrev_b64 v[54:55], v54, v[44:45]\n\t"
+        "v_and_b32 v54, 1, v54\n\t"
+        "v_cmp_eq_u32 vcc, 1, v54\n\t"
+        "s_cbranch_vccz 7f\n\t"
+        "s_mov_b64 exec, vcc\n\t"                     // ---- hits: main.cpp:139-142
+        "s_add_u32 %[tmp], m0, 1\n\t"
+        "v_mov_b32 %[steps], %[tmp]\n\t"
+        "v_mov_b32 %[hitc], v56\n\t"
+        "s_andn2_b64 %[sa], %[sa], vcc\n"
+        "7:\n\t"
+        "s_mov_b64 exec, %[sa]\n\t"
+        "s_cbranch_execz 9f\n"
+        "6:\n\t"                                      // ---- advance_unit (main.cpp:149-153)
+        VK_ADVANCE_UNIT
+        "s_add_u32 m0, m0, 1\n\t"
+        "s_branch 1b\n"
+        "9:\n\t"
+        "s_mov_b64 exec, %[se]"
+        : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [steps] "+v"(steps), [hitc] "+v"(hitc),
+          [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sc] "=&s"(mask_c), [tmp] "=&s"(tmp)
+        : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
+          [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
+          [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [occ] "s"(occ)
+        : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
+    uint32_t iter;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
+    h.steps = (steps == 0xFFFFFFFFu) ? iter : steps;     // lanes still live left at the iteration cap
+    if (hitc != 0xFFFFFFFFu) {
+        const uint32_t x = hitc & 1023u, y = (hitc >> 10) & 1023u, z = hitc >> 20;
+        h.index = x + sx * (y + sy * z);
+        h.payload = h.index;
+    }
+    return h;
+}
+
 __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
 #if VK_FAST_DDA
@@ -1049,7 +1185,12 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
 #else
         if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regular<true>(g, r, ox, oy, oz);
 #endif
-#if VK_ASM_BRICKS
+#if VK_ASM_BRICKS && VK_ASM_WHOLE
+#if VK_BRICK_BLOCKS
+        if (!g.occb) return trace_dense_bricks_asm(g, r, ox, oy, oz);
+#endif
+        return trace_dense_bricks_whole_asm(g, r, ox, oy, oz);
+#elif VK_ASM_BRICKS
         return trace_dense_bricks_asm(g, r, ox, oy, oz);
 #else
         return trace_dense_regular<false>(g, r, ox, oy, oz);
@@ -1469,6 +1610,17 @@ __global__ void __launch_bounds__(256) build_occupancy2(const uint64_t *occ, int
     }
     occ2[rg] = bits;
     if (bits) atomicAdd(nonempty_regions, 1u);
+}
+
+// VK_BRICK_BLOCKS=1: copy of the bricks with a 2x2x2 block of them per 64-byte line (grids of whole 8^3 blocks)
+__global__ void __launch_bounds__(256) block_bricks(const uint64_t *occ, int nbx, int nby, int nbz, uint64_t *occb)
+{
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nb = (size_t)nbx * nby * nbz;
+    if (b >= nb) return;
+    const int bx = (int)(b % (size_t)nbx), by = (int)((b / (size_t)nbx) % (size_t)nby), bz = (int)(b / ((size_t)nbx * nby));
+    const size_t line = (size_t)(bx >> 1) + (size_t)(nbx >> 1) * ((size_t)(by >> 1) + (size_t)(nby >> 1) * (size_t)(bz >> 1));
+    occb[line * 8 + (size_t)((bx & 1) | ((by & 1) << 1) | ((bz & 1) << 2))] = occ[b];
 }
 
 // Region entries of the whole-traversal loop: the occ2 word plus, for an empty region, the key mask of
