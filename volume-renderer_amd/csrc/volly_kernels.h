@@ -1111,8 +1111,8 @@ __device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, c
         "v_lshl_add_u32 v54, v55, 6, v54\n\t"
         "v_lshrrev_b32 v55, 2, v56\n\t"               // bits 0, 10, 20 = bit 2 of x, y, z
         "v_and_b32 v55, 0x100401, v55\n\t"
-        "v_mul_u32_u24 v55, 0x40201, v55\n\t"         // gathered at bits 20..22
-        "v_bfe_u32 v55, v55, 20, 3\n\t"
+        "v_mul_u32_u24 v55, 0x40201, v55\n\t"         // gathered at bits 18..20
+        "v_bfe_u32 v55, v55, 18, 3\n\t"
         "v_lshl_add_u32 v54, v55, 3, v54\n\t"
 #else
         "v_lshrrev_b32 v54, 2, v52\n\t"               // byte offset of the brick word: 8 * (x>>2 + nbx * (y>>2 + nby * (z>>2)))
