@@ -9,9 +9,10 @@ import numpy as np
 import torch
 from __graft_entry__ import load_package
 vra = load_package()
-scene = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", "dragon.off"), 512, dense=False, svo=True)
+RES = int(os.environ.get("FIXED_COST_RES", "1024"))      # 1024: the headline workload (4 x 4K); 512: config 2 (16 x 1080p)
+scene = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", "dragon.off"), RES, dense=False, svo=True)
 gpu = vra.GpuScene.upload_svo(scene.svo, scene.low)
-W, H, nv = 1920, 1080, 16
+W, H, nv = (3840, 2160, 4) if RES == 1024 else (1920, 1080, 16)
 def frames(away):
     out = []
     for k in range(nv):
@@ -19,7 +20,7 @@ def frames(away):
         if away:
             c = np.array([0.5, 0.5, 0.5], np.float32)
             view = vra.look_at((0, 0, 0), c - pos, (0, 0, -1))     # the reference looks along -camDir (main.cpp:219,397)
-        out.append(vra.frame_from_camera(view, pos, (512,) * 3, (128,) * 3, W, H))
+        out.append(vra.frame_from_camera(view, pos, (RES,) * 3, (RES // 4,) * 3, W, H))
     return out
 dev = torch.device("cuda:0")
 planes = {q: torch.empty((nv, H, W), dtype=torch.float32 if q == "depth" else torch.int32, device=dev)

@@ -122,15 +122,6 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
                        d.nbz, occ);
     HIP_TRY(hipGetLastError());
     d.occ = occ;
-#if VK_BRICK_BLOCKS
-    if (((sx | sy | sz) & 7) == 0) {                      // measurement build: the blocked copy the bricks-only loop reads
-        uint64_t *occb = nullptr;
-        if ((rc = dev_alloc(s, (void **)&occb, nb * 8))) return rc;
-        hipLaunchKernelGGL(vk::block_bricks, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, 0, occ, d.nbx, d.nby, d.nbz, occb);
-        HIP_TRY(hipGetLastError());
-        d.occb = occb;
-    }
-#endif
     d.nrx = (d.nbx + 3) / 4; d.nry = (d.nby + 3) / 4; d.nrz = (d.nbz + 3) / 4;
     const size_t nr = (size_t)d.nrx * d.nry * d.nrz;
     uint64_t *occ2 = nullptr;

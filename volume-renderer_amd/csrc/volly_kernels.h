@@ -48,7 +48,9 @@
 // a 32x2 wavefront tile, output rows staged through LDS, an XCD-contiguous block order, several
 // tiles per wavefront, the top of the octree in LDS, the ray-refill and parked-ray frame kernels
 // -- are no longer in this file: DESIGN.md section 5 has their numbers, profiles/r01_ab/ the logs,
-// the history (commit cfca876) the code.
+// the history (commit cfca876) the code.  Round 2's brick layout with a 2x2x2 block of bricks per
+// 64-byte line (-31 % L2 reads, +2.4 % time on the noise volume; profiles/r02_ab/ab_brick_blocks_c3.log)
+// is in commit e1ece63.
 #ifndef VK_FAST_DDA
 #define VK_FAST_DDA 1
 #endif
@@ -69,9 +71,6 @@
 #endif
 #ifndef VK_ASM_WHOLE
 #define VK_ASM_WHOLE 1               // 0: the region loop that leaves for compiled code at bricks with voxels and at the grid's faces
-#endif
-#ifndef VK_BRICK_BLOCKS
-#define VK_BRICK_BLOCKS 0           // 1: the bricks-only loop reads a copy of the bricks laid out 2x2x2 per 64-byte line (measured, not adopted)
 #endif
 #ifndef VK_ASM_EXTRA
 #define VK_ASM_EXTRA 1
@@ -111,7 +110,6 @@ constexpr int kFrameThreads = 64 * VK_WAVE_BLOCK;   // workgroup size of render_
 struct DenseDev {
     const uint64_t *occ;            // one word per 4x4x4 brick, bit = x&3 | (y&3)<<2 | (z&3)<<4
     const uint64_t *occ2;           // one word per 4x4x4 bricks (16^3 voxels): bit set iff that brick has a voxel
-    const uint64_t *occb;           // VK_BRICK_BLOCKS=1 (measurement build) only: the bricks again, 2x2x2 of them per 64-byte line
     const uint4 *occ2x;             // per region {occ2 word, key mask of the largest empty aligned cube (16^3 .. 128^3 voxels) around it, 0}:
                                     // what the whole-traversal loop loads on a region change (build_region_cubes)
     const uint2 *vox;               // the reference's 8-byte voxels, x + sx*(y + sy*z)
@@ -1055,11 +1053,7 @@ __device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, c
     if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
     const uint32_t cap = g.cap;
     const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz;
-#if VK_BRICK_BLOCKS
-    const uint64_t *occ = g.occb;
-#else
     const uint64_t *occ = g.occ;
-#endif
     uint32_t steps = 0xFFFFFFFFu;                         // still live
     uint32_t hitc = 0xFFFFFFFFu;                          // packed cell of the hit
     uint64_t mask_e, mask_a, mask_c;
@@ -1100,21 +1094,6 @@ __device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, c
         "3:\n\t"
         "s_mov_b64 exec, vcc\n\t"
         "s_cbranch_execz 5f\n\t"
-#if VK_BRICK_BLOCKS
-        // measured alternative layout: a 64-byte line holds a 2x2x2 block of bricks (8^3 voxels), lines x fastest:
-        // byte offset = 64 * (x>>3 + nlx * (y>>3 + nly * (z>>3))) + 8 * ((x>>2)&1 | (y>>2)&1 << 1 | (z>>2)&1 << 2)
-        "v_lshrrev_b32 v54, 3, v52\n\t"
-        "v_and_b32 v55, 0xfffffff8, v51\n\t"
-        "v_mad_u32_u24 v54, v54, %[sy], v55\n\t"      // 8 * (y>>3 + nly * (z>>3))
-        "v_mul_u32_u24 v54, v54, %[sx]\n\t"           // 64 * nlx * (...)
-        "v_lshrrev_b32 v55, 3, v50\n\t"
-        "v_lshl_add_u32 v54, v55, 6, v54\n\t"
-        "v_lshrrev_b32 v55, 2, v56\n\t"               // bits 0, 10, 20 = bit 2 of x, y, z
-        "v_and_b32 v55, 0x100401, v55\n\t"
-        "v_mul_u32_u24 v55, 0x40201, v55\n\t"         // gathered at bits 18..20
-        "v_bfe_u32 v55, v55, 18, 3\n\t"
-        "v_lshl_add_u32 v54, v55, 3, v54\n\t"
-#else
         "v_lshrrev_b32 v54, 2, v52\n\t"               // byte offset of the brick word: 8 * (x>>2 + nbx * (y>>2 + nby * (z>>2)))
         "v_and_b32 v55, 0xfffffffc, v51\n\t"
         "v_mad_u32_u24 v54, v54, %[sy], v55\n\t"      // 4 * (y>>2 + nby * (z>>2))
@@ -1122,7 +1101,6 @@ __device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, c
         "v_lshrrev_b32 v54, 1, v54\n\t"
         "v_lshrrev_b32 v55, 2, v50\n\t"
         "v_lshl_add_u32 v54, v55, 3, v54\n\t"
-#endif
         "global_load_dwordx2 v[44:45], v54, %[occ]\n\t"
         "v_mov_b32 v46, v53\n\t"
         "s_waitcnt vmcnt(0)\n"
@@ -1186,9 +1164,6 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
         if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regular<true>(g, r, ox, oy, oz);
 #endif
 #if VK_ASM_BRICKS && VK_ASM_WHOLE
-#if VK_BRICK_BLOCKS
-        if (!g.occb) return trace_dense_bricks_asm(g, r, ox, oy, oz);
-#endif
         return trace_dense_bricks_whole_asm(g, r, ox, oy, oz);
 #elif VK_ASM_BRICKS
         return trace_dense_bricks_asm(g, r, ox, oy, oz);
@@ -1610,17 +1585,6 @@ __global__ void __launch_bounds__(256) build_occupancy2(const uint64_t *occ, int
     }
     occ2[rg] = bits;
     if (bits) atomicAdd(nonempty_regions, 1u);
-}
-
-// VK_BRICK_BLOCKS=1: copy of the bricks with a 2x2x2 block of them per 64-byte line (grids of whole 8^3 blocks)
-__global__ void __launch_bounds__(256) block_bricks(const uint64_t *occ, int nbx, int nby, int nbz, uint64_t *occb)
-{
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nb = (size_t)nbx * nby * nbz;
-    if (b >= nb) return;
-    const int bx = (int)(b % (size_t)nbx), by = (int)((b / (size_t)nbx) % (size_t)nby), bz = (int)(b / ((size_t)nbx * nby));
-    const size_t line = (size_t)(bx >> 1) + (size_t)(nbx >> 1) * ((size_t)(by >> 1) + (size_t)(nby >> 1) * (size_t)(bz >> 1));
-    occb[line * 8 + (size_t)((bx & 1) | ((by & 1) << 1) | ((bz & 1) << 2))] = occ[b];
 }
 
 // Region entries of the whole-traversal loop: the occ2 word plus, for an empty region, the key mask of
