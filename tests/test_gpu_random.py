@@ -114,3 +114,45 @@ def test_the_random_cases_reach_hits_and_misses(vra, ora):
     assert (want["hit_index"] != MISS).sum() > 200 and (want["hit_index"] == MISS).sum() > 200
     assert (want["steps_lo"] > 0).sum() > 1000 and (want["steps_hi"] > 0).sum() > 200
     scene.close()
+
+
+def test_large_empty_cubes_and_run_ahead(vra, ora):
+    """The whole-traversal loop keeps a lane quiet across the largest aligned empty cube around its
+    region (32^3, 64^3, 128^3) and runs four steps ahead without looking when every lane is deep inside
+    one: a 256^3 grid that is almost empty -- a few voxels in a corner, a thin slab, a lone voxel in
+    the middle of a 128^3 void -- traversed from the camera (naive) and behind its 64^3 beam grid, from
+    outside, from inside a void, along the axes and diagonally across cube corners."""
+    rng = np.random.default_rng(5)
+    n = 256
+    vox = np.zeros((n, n, n, 8), np.uint8)
+    fill = np.zeros((n, n, n), bool)
+    fill[3:9, 2:5, 250:255] = True                       # a clump in one corner
+    fill[200, 40:220:3, 30:230:5] = True                 # a perforated slab
+    fill[64, 64, 192] = True                             # one voxel in the middle of an otherwise empty 128^3 octant
+    fill[rng.integers(130, 250, 40), rng.integers(130, 250, 40), rng.integers(0, 120, 40)] = True
+    k = int(fill.sum())
+    vox[fill, 0:3] = rng.integers(0, 256, (k, 3), dtype=np.uint8)
+    vox[fill, 3] = 255
+    vox[fill, 4:7] = rng.integers(0, 256, (k, 3), dtype=np.uint8)
+    low = _low_of(vox, 4)
+    scene = vra.HostScene.from_dense(vox, low, svo=False)
+    gpu = vra.GpuScene.upload_dense(scene.target, scene.low)
+    assert gpu.dda_loops() == "target asm-regions, low asm-regions"
+    hi, lo = (n,) * 3, (n // 4,) * 3
+    cams = [((1.6, -0.4, 1.3), (0.2, 0.6, 0.4)), ((0.25, 0.25, 0.75), (0.9, 0.9, 0.1)), ((-0.5, 0.5, 0.5), (1.0, 0.5, 0.5)),
+            ((0.5, 0.5, -0.7), (0.5, 0.5, 1.0)), ((-0.3, -0.3, -0.3), (1.0, 1.0, 1.0)), ((0.75, 0.26, 0.24), (0.0, 0.3, 0.8))]
+    total_hits = longest = 0
+    for i, (pos, center) in enumerate(cams):
+        eye, at = np.array(pos, np.float32), np.array(center, np.float32)
+        up = (0, 0, -1) if abs((at - eye)[2]) < 0.9 * np.linalg.norm(at - eye) else (0, 1, 0)     # lookAt needs up not parallel to the view
+        view = vra.look_at(eye, 2 * eye - at, up)             # the reference looks along -camDir (main.cpp:219,397)
+        for naive in (True, False):
+            f = vra.frame_from_camera(view, np.array(pos, np.float32), hi, lo, 120, 88, naive=naive)
+            want = ora.render_frame(f, low=scene.low, target=scene.target, planes=ALL, threads=16)
+            got = gpu.render(f, planes=ALL)
+            assert_planes_equal({p: v[0] for p, v in got.items()}, want, f"camera {i} naive={naive}")
+            total_hits += int((want["hit_index"] != MISS).sum())
+            longest = max(longest, int(want["steps_hi"].max() if naive else want["steps_lo"].max()))
+    assert total_hits > 500 and longest > 200
+    gpu.close()
+    scene.close()
