@@ -69,7 +69,7 @@ VARDIR := $(LIBDIR)/variants
 VARIANTS ?= experimental:-DVK_EXPERIMENTAL=1 checked:-DVK_FAST_DDA=0 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 waves4:-DVK_WAVE_BLOCK=4 \
             longdiv:-DVK_SHORT_DIV=0 index32:-DVK_INDEX24=0 ckpt4:-DVK_CKPT_STRIDE=4 packc:-DVK_PACK_ASM=0 noasm:-DVK_ASM_QUIET=0 \
             noasmextra:-DVK_ASM_EXTRA=0 noasmbricks:-DVK_ASM_BRICKS=0 nobfi:-DVK_SIGN_BFI=0 w6:-DVK_PROBE_WAVES=6 w4:-DVK_PROBE_WAVES=4 \
-            slp:-fslp-vectorize
+            slp:-fslp-vectorize ahead0:-DVK_RUN_AHEAD=0 count:-DVK_COUNT=1
 variants:
 	@mkdir -p $(VARDIR)
 	for v in $(VARIANTS); do \

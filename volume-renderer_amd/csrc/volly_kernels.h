@@ -36,7 +36,7 @@
 //   VK_INDEX24=0      32-bit multiplies for the brick / region index in the regular loop
 //   VK_PACK_ASM=0     let the compiler choose the instructions that pack a cell
 //   VK_ASM_QUIET=0    the compiled region loop only (no assembly loop for the quiet steps)
-//   VK_ASM_WHOLE=0    the region loop of round 1, which hands bricks with voxels and grid exits to compiled code
+//   VK_RUN_AHEAD=K    steps the region loop takes without looking when every lane is deep inside its empty cube (0: never)
 //   VK_ASM_EXTRA=0    the compiled loop for the serial adds past a checkpoint
 //   VK_ASM_BRICKS=0   the compiled loop for grids without the region level
 //   VK_SIGN_BFI=0     sign(d) * eps by compares, conversion and multiply also for regular wavefronts
@@ -50,7 +50,8 @@
 // -- are no longer in this file: DESIGN.md section 5 has their numbers, profiles/r01_ab/ the logs,
 // the history (commit cfca876) the code.  Round 2's brick layout with a 2x2x2 block of bricks per
 // 64-byte line (-31 % L2 reads, +2.4 % time on the noise volume; profiles/r02_ab/ab_brick_blocks_c3.log)
-// is in commit e1ece63.
+// is in commit e1ece63; round 1's assembly loops, which handed hits and grid exits to compiled code, are
+// in commit 7641e49 (profiles/r02_ab/r02_ab_whole_c*.log).
 #ifndef VK_FAST_DDA
 #define VK_FAST_DDA 1
 #endif
@@ -68,9 +69,6 @@
 #endif
 #ifndef VK_ASM_QUIET
 #define VK_ASM_QUIET 1
-#endif
-#ifndef VK_ASM_WHOLE
-#define VK_ASM_WHOLE 1               // 0: the region loop that leaves for compiled code at bricks with voxels and at the grid's faces
 #endif
 #ifndef VK_ASM_EXTRA
 #define VK_ASM_EXTRA 1
@@ -440,197 +438,17 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
     return h;
 }
 
-// trace_dense_regular<true> with the common steps in assembly (VK_ASM_QUIET).
+// trace_dense_regular<true> in assembly, with nothing left to compiled code (VK_ASM_QUIET).
 //
-// A lane is *quiet* while (cell & wmask) == watch: watch / wmask name its 16^3 region while that
-// region is known to be empty, its 4^3 brick while the region holds voxels but the brick does
-// not, and watch is 0xFFFFFFFF (which no key equals) inside a brick with voxels.  Measured: in
-// 57 % of the wave-steps of the headline workload every live lane is quiet
-// (profiles/r01_ab/count_quiet_steps.log, count_asm_loop_exits.log); such a step needs no per-lane
-// test at all, and most of the others are a lane entering another region or another empty brick.
-// The assembly loop runs
-//   * quiet steps back to back: 29 vector and 5 scalar instructions each (35 and ~20 compiled);
-//   * region changes inside the grid (bounds test, load of the region word) and moves to
-//     another empty brick for the lanes that need them, under an exec mask of its own,
-// and leaves -- state consistent, the step not yet taken -- when a lane leaves the grid, enters a
-// brick that holds voxels, or the iteration cap is reached; the per-lane C++ code below then
-// handles that one step for every lane and re-enters.
-//
-// Registers: v47-v55 are the loop's own temporaries (clobbers).  Its three exec masks are
-// operands, so that the compiler places them: fixed high scalar registers cost the kernel its
-// eighth wavefront per SIMD (800 scalar registers per SIMD: 8 waves need <= 96 each).  The iteration
-// number lives in m0: the compiler will not keep a loop-carried value of a divergent loop in a
-// scalar register ("illegal VGPR to SGPR copy"), and nothing else in these kernels uses m0 (no
-// LDS, no indexed registers, no messages; tests/test_m0_is_ours.py reads the assembly).
-__device__ __forceinline__ Hit trace_dense_regular_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
-{
-    Hit h;
-    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
-    h.steps = 0;
-    h.index = VOLLY_MISS_INDEX;
-    h.payload = VOLLY_MISS_INDEX;
-    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
-    uint32_t last_brick = 0xFFFFFFFFu, w_lo = 0, w_hi = 0;
-    uint32_t last_region = 0xFFFFFFFFu;
-    uint64_t rw = 0;                                     // the region word: which of the region's 64 bricks hold voxels
-    uint32_t watch = 0xFFFFFFFFu, wmask = 0xFF0FC3F0u;
-    uint32_t live = 1;
-    const uint32_t cap = g.cap;
-    const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz, nrx = (uint32_t)g.nrx, nry = (uint32_t)g.nry;
-    const uint64_t *occ2 = g.occ2;
-    asm volatile("s_mov_b32 m0, 0");
-    for (;;) {
-        uint32_t c;
-        uint64_t mask_a, mask_b, mask_c;                  // exec masks of the loop's own
-        asm volatile(
-            "1:\n\t"                                      // ---- one step: sample point, cell, key
-            "v_add_f32 v47, %[cx], %[ex]\n\t"
-            "v_add_f32 v48, %[cy], %[ey]\n\t"
-            "v_add_f32 v49, %[cz], %[ez]\n\t"
-            "v_cvt_i32_f32 v50, v47\n\t"
-            "v_cvt_i32_f32 v51, v48\n\t"
-            "v_cvt_i32_f32 v52, v49\n\t"
-            "v_lshl_or_b32 %[c], v51, 10, v50\n\t"
-            "v_lshl_or_b32 %[c], v52, 20, %[c]\n\t"
-            "v_and_b32 v53, %[wmask], %[c]\n\t"
-            "v_cmp_ne_u32 vcc, v53, %[watch]\n\t"
-            "s_cbranch_vccnz 3f\n\t"
-            "s_cmp_ge_u32 m0, %[cap]\n\t"
-            "s_cbranch_scc1 9f\n"
-            "2:\n\t"                                      // ---- advance_unit (main.cpp:149-153), every live lane
-            "v_floor_f32 v53, v47\n\t"
-            "v_floor_f32 v54, v48\n\t"
-            "v_floor_f32 v55, v49\n\t"
-            "v_add_f32 v53, v53, %[hx]\n\t"
-            "v_add_f32 v54, v54, %[hy]\n\t"
-            "v_add_f32 v55, v55, %[hz]\n\t"
-            "v_sub_f32 v53, v53, %[cx]\n\t"
-            "v_sub_f32 v54, v54, %[cy]\n\t"
-            "v_sub_f32 v55, v55, %[cz]\n\t"
-            "v_mul_f32 v53, v53, %[ix]\n\t"
-            "v_mul_f32 v54, v54, %[iy]\n\t"
-            "v_mul_f32 v55, v55, %[iz]\n\t"
-            "v_min3_f32 v53, v53, v54, v55\n\t"
-            "v_mul_f32 v54, v53, %[dx]\n\t"
-            "v_mul_f32 v55, v53, %[dy]\n\t"
-            "v_mul_f32 v53, v53, %[dz]\n\t"
-            "v_add_f32 %[cx], v54, %[cx]\n\t"
-            "v_add_f32 %[cy], v55, %[cy]\n\t"
-            "v_add_f32 %[cz], v53, %[cz]\n\t"
-            "s_add_u32 m0, m0, 1\n\t"
-            "s_branch 1b\n"
-            "3:\n\t"                                      // ---- vcc = the lanes that are not quiet
-            "s_cmp_ge_u32 m0, %[cap]\n\t"
-            "s_cbranch_scc1 9f\n\t"
-            "s_mov_b64 %[sa], exec\n\t"
-            "s_mov_b64 exec, vcc\n\t"
-            "v_and_b32 v53, 0xff0fc3f0, %[c]\n\t"         // region key
-            "v_cmp_ne_u32 vcc, v53, %[lastr]\n\t"
-            "s_and_saveexec_b64 %[sb], vcc\n\t"        // lanes in a new region
-            "s_cbranch_execz 5f\n\t"
-            "v_cmp_gt_u32 vcc, %[sx], v50\n\t"
-            "v_cmp_gt_u32 %[sc], %[sy], v51\n\t"
-            "s_and_b64 vcc, vcc, %[sc]\n\t"
-            "v_cmp_gt_u32 %[sc], %[sz], v52\n\t"
-            "s_and_b64 vcc, vcc, %[sc]\n\t"
-            "s_xor_b64 %[sc], vcc, exec\n\t"           // a lane left the grid: the C++ code ends it
-            "s_cbranch_scc1 8f\n\t"
-            "v_lshrrev_b32 v54, 4, v52\n\t"               // region index x>>4 + nrx * (y>>4 + nry * (z>>4))
-            "v_lshrrev_b32 v55, 4, v51\n\t"
-            "v_mad_u32_u24 v54, v54, %[nry], v55\n\t"
-            "v_lshrrev_b32 v55, 4, v50\n\t"
-            "v_mad_u32_u24 v54, v54, %[nrx], v55\n\t"
-            "v_lshlrev_b32 v54, 3, v54\n\t"
-            "global_load_dwordx2 %[rw], v54, %[occ2]\n\t"
-            "v_mov_b32 %[lastr], v53\n\t"
-            "s_waitcnt vmcnt(0)\n"
-            "5:\n\t"
-            "s_mov_b64 exec, %[sb]\n\t"                // the lanes that are not quiet again
-            "v_mov_b32 v54, 0xff0fc3f0\n\t"
-            "v_cmp_eq_u64 vcc, 0, %[rw]\n\t"              // empty region: quiet until the lane leaves it
-            "s_nop 1\n\t"                                 // gfx950: a vector compare's vcc needs two wait states before a vector instruction reads it
-            "v_cndmask_b32 %[watch], %[watch], v53, vcc\n\t"
-            "v_cndmask_b32 %[wmask], %[wmask], v54, vcc\n\t"
-            "s_andn2_b64 exec, exec, vcc\n\t"             // lanes in a region with voxels: look at the brick's bit
-            "s_cbranch_execz 7f\n\t"
-            "v_lshrrev_b32 v54, 2, %[c]\n\t"
-            "v_and_b32 v54, 0x300c03, v54\n\t"
-            "v_mul_u32_u24 v54, 0x40404, v54\n\t"
-            "v_bfe_u32 v54, v54, 18, 6\n\t"
-            "v_lshrrev_b64 v[54:55], v54, %[rw]\n\t"
-            "v_and_b32 v54, 1, v54\n\t"
-            "v_cmp_eq_u32 vcc, 1, v54\n\t"
-            "s_cbranch_vccnz 8f\n\t"                      // a brick with voxels: the C++ code tests the voxel
-            "v_and_b32 %[watch], 0xffcff3fc, %[c]\n\t"    // an empty brick: quiet until the lane leaves it
-            "v_mov_b32 %[wmask], 0xffcff3fc\n"
-            "7:\n\t"
-            "s_mov_b64 exec, %[sa]\n\t"
-            "s_branch 2b\n"
-            "8:\n\t"
-            "s_mov_b64 exec, %[sa]\n"
-            "9:"
-            : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [c] "=&v"(c),
-              [lastr] "+v"(last_region), [rw] "+v"(rw), [watch] "+v"(watch), [wmask] "+v"(wmask),
-              [sa] "=&s"(mask_a), [sb] "=&s"(mask_b), [sc] "=&s"(mask_c)
-            : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
-              [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-              [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [nrx] "s"(nrx), [nry] "s"(nry), [occ2] "s"(occ2)
-            : "vcc", "scc", "memory", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
-        uint32_t iter;
-        asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
-        if (iter >= cap) { h.steps = iter; break; }      // uniform
-        // the step the loop stopped at, for every live lane (everything it may already have done
-        // for some of them -- region word, watch -- is found done again here)
-        const float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
-        const int x = (int)px, y = (int)py, z = (int)pz;
-        const uint32_t region = c & 0xFF0FC3F0u;
-        if (region != last_region) {
-            bool inside = ((uint32_t)x < sx) & ((uint32_t)y < sy) & ((uint32_t)z < sz);
-            if (inside) {
-                rw = occ2[cell_index24(x >> 4, y >> 4, z >> 4, g.nrx, g.nry)];
-                last_region = region;
-                watch = region;                          // quiet until the lane leaves this region ...
-                wmask = 0xFF0FC3F0u;
-            } else {                                     // left the grid: main.cpp:126-135
-                rw = 0;
-                live = 0;
-                h.steps = iter;
-            }
-        }
-        if (rw != 0) {                                   // ... unless the region holds voxels:
-            const uint32_t r_lo = (uint32_t)rw, r_hi = (uint32_t)(rw >> 32);
-            const uint32_t brick = c & 0xFFCFF3FCu;
-            watch = brick;                               // then quiet until it leaves this 4^3 brick ...
-            wmask = 0xFFCFF3FCu;
-            if (test_word(r_lo, r_hi, gather_bits((c >> 2) & 0x00300C03u))) {      // ... unless the brick holds voxels:
-                watch = 0xFFFFFFFFu;                     // then every step is looked at
-                if (brick != last_brick) {
-                    uint64_t bits = g.occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
-                    w_lo = (uint32_t)bits;
-                    w_hi = (uint32_t)(bits >> 32);
-                    last_brick = brick;
-                }
-                if (test_word(w_lo, w_hi, gather_bits(c & 0x00300C03u))) {   // main.cpp:139-142
-                    live = 0;
-                    h.steps = iter + 1;
-                    h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
-                    h.payload = h.index;
-                }
-            }
-        }
-        if (!live) break;
-        advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
-        asm volatile("s_add_u32 m0, m0, 1" : : : "scc");
-    }
-    return h;
-}
-
-// The same traversal with NOTHING left to compiled code (VK_ASM_WHOLE, the default): the loop above
-// leaves for the per-lane C++ block whenever a lane enters a brick that holds voxels or leaves the
-// grid -- about 95 vector instructions for the whole wavefront each time, ~1.5 M times per launch
-// of the headline workload (a tenth of its vector instructions).  Here those two events are
-// handled in place, under exec masks of the loop's own, and a finished lane simply drops out of
-// the loop's live mask:
+// A lane is *quiet* while (cell & wmask) == watch: watch / wmask name the largest empty aligned cube
+// (16^3 .. 128^3 voxels) around its region while that region is empty, its 4^3 brick while the region
+// holds voxels but the brick does not, and watch is 0xFFFFFFFF (which no key equals) inside a brick
+// with voxels.  A step in which every live lane is quiet needs no per-lane test at all: 29 vector and
+// 5 scalar instructions (35 and ~20 compiled).  Round 1's form of this loop (commit 7641e49 and before)
+// left for a per-lane C++ block whenever a lane entered a brick that holds voxels or left the grid --
+// about 95 vector instructions for the whole wavefront each time, ~1.5 M times per launch of the
+// headline workload.  Here those events are handled in place, under exec masks of the loop's own, and
+// a finished lane simply drops out of the loop's live mask:
 //   * a lane whose new region lies outside the grid (main.cpp:126-135) records its step count;
 //   * a lane in a brick that holds voxels loads the brick word when the brick is new to it and
 //     tests its cell's bit every step (watch = none); a set bit is the hit (main.cpp:139-142):
@@ -904,145 +722,14 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
     return h;
 }
 
-// trace_dense_regular<false> (bricks only: grids whose 16^3 regions nearly all hold voxels, e.g.
-// the noise volume) with the whole step in assembly (VK_ASM_BRICKS).  In such a grid some lane of
-// the wavefront enters a new 4^3 brick on almost every step, so there are no quiet steps to run
-// ahead with; what the assembly saves is the exec-mask bookkeeping of the compiled per-lane
-// tests: a step is the sample point and cell (11 vector instructions), for the lanes in a new
-// brick the bounds test, brick index and load of its word (9 + the load), for the lanes whose
-// brick holds voxels the test of the cell's bit (9), and the advance (19).  It leaves -- state
-// consistent, the step not yet taken -- when a lane leaves the grid or samples a voxel (the
-// per-lane C++ code below ends that lane) or at the iteration cap.  Same registers and m0
-// convention as trace_dense_regular_asm.
-__device__ __forceinline__ Hit trace_dense_bricks_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
-{
-    Hit h;
-    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
-    h.steps = 0;
-    h.index = VOLLY_MISS_INDEX;
-    h.payload = VOLLY_MISS_INDEX;
-    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
-    uint32_t last_brick = 0xFFFFFFFFu;
-    uint64_t w = 0;                                      // the brick word: which of the brick's 64 cells hold a voxel
-    uint32_t live = 1;
-    const uint32_t cap = g.cap;
-    const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz, nbx = (uint32_t)g.nbx, nby = (uint32_t)g.nby;
-    const uint64_t *occ = g.occ;
-    asm volatile("s_mov_b32 m0, 0");
-    for (;;) {
-        uint32_t c;
-        uint64_t mask_a, mask_b;
-        asm volatile(
-            "1:\n\t"                                      // ---- sample point, cell, brick key
-            "v_add_f32 v47, %[cx], %[ex]\n\t"
-            "v_add_f32 v48, %[cy], %[ey]\n\t"
-            "v_add_f32 v49, %[cz], %[ez]\n\t"
-            "v_cvt_i32_f32 v50, v47\n\t"
-            "v_cvt_i32_f32 v51, v48\n\t"
-            "v_cvt_i32_f32 v52, v49\n\t"
-            "v_lshl_or_b32 %[c], v51, 10, v50\n\t"
-            "v_lshl_or_b32 %[c], v52, 20, %[c]\n\t"
-            "s_cmp_ge_u32 m0, %[cap]\n\t"
-            "s_cbranch_scc1 9f\n\t"
-            "v_and_b32 v53, 0xffcff3fc, %[c]\n\t"
-            "v_cmp_ne_u32 vcc, v53, %[lastb]\n\t"
-            "s_cbranch_vccz 4f\n\t"
-            "s_and_saveexec_b64 %[sa], vcc\n\t"           // ---- lanes in a new brick
-            "v_cmp_gt_u32 vcc, %[sx], v50\n\t"
-            "v_cmp_gt_u32 %[sb], %[sy], v51\n\t"
-            "s_and_b64 vcc, vcc, %[sb]\n\t"
-            "v_cmp_gt_u32 %[sb], %[sz], v52\n\t"
-            "s_and_b64 vcc, vcc, %[sb]\n\t"
-            "s_xor_b64 %[sb], vcc, exec\n\t"              // a lane left the grid: the C++ code ends it
-            "s_cbranch_scc1 8f\n\t"
-            "v_lshrrev_b32 v54, 2, v52\n\t"               // brick index x>>2 + nbx * (y>>2 + nby * (z>>2))
-            "v_lshrrev_b32 v55, 2, v51\n\t"
-            "v_mad_u32_u24 v54, v54, %[nby], v55\n\t"
-            "v_lshrrev_b32 v55, 2, v50\n\t"
-            "v_mad_u32_u24 v54, v54, %[nbx], v55\n\t"
-            "v_lshlrev_b32 v54, 3, v54\n\t"
-            "global_load_dwordx2 %[w], v54, %[occ]\n\t"
-            "v_mov_b32 %[lastb], v53\n\t"
-            "s_waitcnt vmcnt(0)\n\t"
-            "s_mov_b64 exec, %[sa]\n"
-            "4:\n\t"                                      // ---- lanes whose brick holds voxels: the cell's bit
-            "v_cmp_ne_u64 vcc, 0, %[w]\n\t"
-            "s_cbranch_vccz 6f\n\t"
-            "s_and_saveexec_b64 %[sa], vcc\n\t"
-            "v_and_b32 v54, 0x300c03, %[c]\n\t"
-            "v_mul_u32_u24 v54, 0x40404, v54\n\t"
-            "v_bfe_u32 v54, v54, 18, 6\n\t"
-            "v_lshrrev_b64 v[54:55], v54, %[w]\n\t"
-            "v_and_b32 v54, 1, v54\n\t"
-            "v_cmp_eq_u32 vcc, 1, v54\n\t"
-            "s_cbranch_vccnz 8f\n\t"                      // a voxel: the C++ code records the hit
-            "s_mov_b64 exec, %[sa]\n"
-            "6:\n\t"                                      // ---- advance_unit (main.cpp:149-153)
-            "v_floor_f32 v53, v47\n\t"
-            "v_floor_f32 v54, v48\n\t"
-            "v_floor_f32 v55, v49\n\t"
-            "v_add_f32 v53, v53, %[hx]\n\t"
-            "v_add_f32 v54, v54, %[hy]\n\t"
-            "v_add_f32 v55, v55, %[hz]\n\t"
-            "v_sub_f32 v53, v53, %[cx]\n\t"
-            "v_sub_f32 v54, v54, %[cy]\n\t"
-            "v_sub_f32 v55, v55, %[cz]\n\t"
-            "v_mul_f32 v53, v53, %[ix]\n\t"
-            "v_mul_f32 v54, v54, %[iy]\n\t"
-            "v_mul_f32 v55, v55, %[iz]\n\t"
-            "v_min3_f32 v53, v53, v54, v55\n\t"
-            "v_mul_f32 v54, v53, %[dx]\n\t"
-            "v_mul_f32 v55, v53, %[dy]\n\t"
-            "v_mul_f32 v53, v53, %[dz]\n\t"
-            "v_add_f32 %[cx], v54, %[cx]\n\t"
-            "v_add_f32 %[cy], v55, %[cy]\n\t"
-            "v_add_f32 %[cz], v53, %[cz]\n\t"
-            "s_add_u32 m0, m0, 1\n\t"
-            "s_branch 1b\n"
-            "8:\n\t"
-            "s_mov_b64 exec, %[sa]\n"
-            "9:"
-            : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [c] "=&v"(c),
-              [lastb] "+v"(last_brick), [w] "+v"(w), [sa] "=&s"(mask_a), [sb] "=&s"(mask_b)
-            : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
-              [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-              [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [nbx] "s"(nbx), [nby] "s"(nby), [occ] "s"(occ)
-            : "vcc", "scc", "memory", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
-        uint32_t iter;
-        asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
-        if (iter >= cap) { h.steps = iter; break; }      // uniform
-        // the step the loop stopped at, for every live lane
-        const float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
-        const int x = (int)px, y = (int)py, z = (int)pz;
-        const uint32_t brick = c & 0xFFCFF3FCu;
-        if (brick != last_brick) {
-            bool inside = ((uint32_t)x < sx) & ((uint32_t)y < sy) & ((uint32_t)z < sz);
-            if (inside) {
-                w = occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
-                last_brick = brick;
-            } else {                                     // left the grid: main.cpp:126-135
-                live = 0;
-                h.steps = iter;
-            }
-        }
-        if (live && test_word((uint32_t)w, (uint32_t)(w >> 32), gather_bits(c & 0x00300C03u))) {   // main.cpp:139-142
-            live = 0;
-            h.steps = iter + 1;
-            h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
-            h.payload = h.index;
-        }
-        if (!live) break;
-        advance_unit(r, px, py, pz, h.cx, h.cy, h.cz);
-        asm volatile("s_add_u32 m0, m0, 1" : : : "scc");
-    }
-    return h;
-}
-
-// trace_dense_bricks_asm with nothing left to compiled code (VK_ASM_WHOLE): in a grid without the region
-// level (the noise volume) ray lengths scatter, so nearly every lane of a wavefront ends at a step of its
-// own, and each such end used to send the whole wavefront through the per-lane C++ block.  Here a lane
-// that leaves the grid or samples a voxel records its result under an exec mask and drops out of the
-// loop's live mask.  Fixed registers: v47-v55 temporaries, v56 packed cell, v46 brick key, v44-v45 brick word.
+// trace_dense_regular<false> (bricks only: grids whose 16^3 regions nearly all hold voxels, e.g. the
+// noise volume) in assembly, with nothing left to compiled code (VK_ASM_BRICKS).  In such a grid some
+// lane of the wavefront enters a new 4^3 brick on almost every step, so there are no quiet steps to run
+// ahead with; what the assembly saves is the exec-mask bookkeeping of the compiled per-lane tests: a
+// step is the sample point and cell (11 vector instructions), for the lanes in a new brick the bounds
+// test, brick offset and load of its word, for the lanes whose brick holds voxels the test of the cell's
+// bit, and the advance (19).  A lane that leaves the grid or samples a voxel records its result under an
+// exec mask and drops out of the loop's live mask.  Fixed registers: v47-v55 temporaries, v56 packed cell, v46 brick key, v44-v45 brick word.
 __device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
 {
     Hit h;
@@ -1156,17 +843,13 @@ __device__ __forceinline__ Hit trace_dense(const DenseDev &g, const Ray &r, floa
     // one path per wavefront, so the two loops never run interleaved in a wave
     if (grid_is_regular(g) && __all(ray_is_regular(r))) {
         // the 16^3 region level is chosen per grid at upload (DenseDev::use_regions)
-#if VK_ASM_QUIET && VK_ASM_WHOLE
+#if VK_ASM_QUIET
         if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regions_whole_asm(g, r, ox, oy, oz);
-#elif VK_ASM_QUIET
-        if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regular_asm(g, r, ox, oy, oz);
 #else
         if (VK_OCC_LEVELS == 2 && g.use_regions) return trace_dense_regular<true>(g, r, ox, oy, oz);
 #endif
-#if VK_ASM_BRICKS && VK_ASM_WHOLE
+#if VK_ASM_BRICKS
         return trace_dense_bricks_whole_asm(g, r, ox, oy, oz);
-#elif VK_ASM_BRICKS
-        return trace_dense_bricks_asm(g, r, ox, oy, oz);
 #else
         return trace_dense_regular<false>(g, r, ox, oy, oz);
 #endif
