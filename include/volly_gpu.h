@@ -154,7 +154,7 @@ void  volly_gpu_host_free(void *p);
  * without waiting.  `frames` is consumed before the call returns.
  * A scene's per-call scratch is shared by its calls: calls on ONE stream follow each other; a call
  * on a DIFFERENT stream than the previous call on this scene is made to wait (on the device) for
- * everything queued on that previous stream, which must still exist.  Calls on one scene from
+ * that previous call's kernels (the previous stream may have been destroyed since).  Calls on one scene from
  * several host threads at once are not supported (the handle is not re-entrant). */
 int volume_gpu_render_device(volly_gpu_scene *scene, const volly_frame_desc *frames, int n_frames,
                              const volly_outputs *outs, void *hip_stream);

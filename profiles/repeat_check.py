@@ -18,6 +18,7 @@ def main():
     a = ap.parse_args()
     vra = load_package()
     p = dict(B.PRESETS[a.config])
+    p["scene"] = p["scene"].split(",")[0]
     res, W, H, nv = p["res"], p["width"], p["height"], p["views"]
     dense = p["target"] == "dense"
     if p["scene"] == "noise":

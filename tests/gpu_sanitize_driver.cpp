@@ -85,6 +85,24 @@ static int render_all_ways(volly_gpu_scene *sc, int res_hi, int res_lo)
     std::vector<uint32_t> back((size_t)40 * 21 * N);
     CHECK(hipMemcpy(back.data(), d_rgba, back.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
     CHECK(std::memcmp(back.data(), b.rgba.data(), back.size() * 4) == 0);
+    // the entry point that allocates nothing, then the ordinary one on ANOTHER stream (the scene's
+    // scratch is handed from stream to stream), then the no-alloc size limit
+    hipStream_t st2;
+    CHECK(hipStreamCreate(&st2) == hipSuccess);
+    CHECK(hipMemset(d_rgba, 0, back.size() * 4) == hipSuccess);
+    CHECK(volume_gpu_render_device_noalloc(sc, fr.data(), N, &od, st) == VOLLY_OK);
+    CHECK(hipStreamSynchronize(st) == hipSuccess);
+    CHECK(hipMemcpy(back.data(), d_rgba, back.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(std::memcmp(back.data(), b.rgba.data(), back.size() * 4) == 0);
+    CHECK(volume_gpu_render_device(sc, fr.data(), N, &od, st) == VOLLY_OK);
+    CHECK(volume_gpu_render_device(sc, fr.data(), N, &od, st2) == VOLLY_OK);
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    CHECK(hipMemcpy(back.data(), d_rgba, back.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
+    CHECK(std::memcmp(back.data(), b.rgba.data(), back.size() * 4) == 0);
+    volly_frame_desc huge = fr[0];
+    huge.width = huge.tile_w = 7680; huge.height = huge.tile_h = 4320; huge.x0 = huge.y0 = 0;
+    CHECK(volume_gpu_render_device_noalloc(sc, &huge, 1, &od, st) == VOLLY_E_ARG);
+    (void)hipStreamDestroy(st2);
     (void)hipFree(d_rgba);
     (void)hipStreamDestroy(st);
 

@@ -286,16 +286,12 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     float *d_ckpt = fixed_ckpt;
     if (!no_alloc) {
         // The scene's scratch (descriptors, checkpoints) is reused by every call.  Calls on one stream
-        // are ordered by the stream; when the stream CHANGES, the new stream first waits for everything
-        // queued on the previous one, or its pre-pass would overwrite what the previous frame kernel
-        // is still reading.  Nothing is recorded on the common path (same stream every call).
+        // are ordered by the stream; when the stream CHANGES, the new stream first waits for the event
+        // the previous call recorded behind its last kernel, or its pre-pass would overwrite what that
+        // kernel is still reading.  (The previous stream's handle is never touched again: the caller
+        // may have destroyed it, and HIP faults on a dead handle.)
         if (s->scratch_in_use && s->scratch_stream != stream) {
-            bool ordered = false;
-            if (!s->scratch_event) (void)hipEventCreateWithFlags(&s->scratch_event, hipEventDisableTiming);
-            if (s->scratch_event && hipEventRecord(s->scratch_event, s->scratch_stream) == hipSuccess &&
-                hipStreamWaitEvent(stream, s->scratch_event, 0) == hipSuccess)
-                ordered = true;
-            if (!ordered) {                               // e.g. the previous stream no longer exists
+            if (hipStreamWaitEvent(stream, s->scratch_event, 0) != hipSuccess) {
                 (void)hipGetLastError();
                 HIP_TRY(hipDeviceSynchronize());
             }
@@ -393,6 +389,10 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
                            d_ckpt, o);
     HIP_TRY(hipGetLastError());
     if (e1) HIP_TRY(hipEventRecord(e1, stream));
+    if (!no_alloc) {                                      // what a later call on another stream waits for
+        if (!s->scratch_event) HIP_TRY(hipEventCreateWithFlags(&s->scratch_event, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(s->scratch_event, stream));
+    }
     return VOLLY_OK;
 }
 
