@@ -250,6 +250,18 @@ int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leav
  * 15 the same for the LOW (beam) grid, 0 = no low grid. */
 int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
 
+/* Sky tiles (no reference counterpart: the reference traces every pixel, main.cpp:252-287).  For one
+ * frame of this scene: the pixel rectangle {x_lo, x_hi, y_lo, y_hi} -- inclusive, relative to the
+ * frame's sub-rectangle -- OUTSIDE of which every ray provably ends both passes at its first bounds
+ * test (0 steps, no hit, depth +inf, pixel 255,0,0,0).  8x8 tiles that lie wholly outside it write
+ * those values without setting their rays up, unless pt_end is requested.  The rectangle is the
+ * bounding box of the projected corners of both grids, widened by one cell and four pixels; it is
+ * the whole sub-rectangle (no cull) when a corner is beside or behind the camera, for
+ * VOLLY_FRAME_RAYTRACE frames, and in beam mode when the frame's low and target constants do not
+ * describe the same rays.  x_lo > x_hi or y_lo > y_hi: nothing can be hit.  VOLLY_SKY_CULL=0 in the
+ * environment at scene creation switches the shortcut off. */
+int volly_gpu_sky_rect(const volly_gpu_scene *scene, const volly_frame_desc *frame, int32_t rect[4]);
+
 void        volly_gpu_free(volly_gpu_scene *scene);
 const char *volly_gpu_last_error(void);
 int         volly_gpu_abi_version(void);

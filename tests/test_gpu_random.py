@@ -93,10 +93,12 @@ def test_random_scene_camera_frame(vra, ora, case):
         for f in frames:
             f.x0, f.y0, f.tile_w, f.tile_h = x0, y0, tw, th
     got = gpu.render(frames, planes=ALL)
+    five = gpu.render(frames)          # without pt_end the frame kernel may skip the set-up of sky tiles (sky_rect, volly_gpu.hip)
     for i, f in enumerate(frames):
         want = (ora.render_frame(f, low=scene.low, svo=scene.svo, planes=ALL) if use_svo
                 else ora.render_frame(f, low=scene.low, target=scene.target, planes=ALL))
         assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"case {case} frame {i} shape {shape} flags {f.flags}")
+        assert_planes_equal({k: v[i] for k, v in five.items()}, want, f"case {case} frame {i} shape {shape} flags {f.flags}, five planes")
     gpu.close()
     scene.close()
 
@@ -151,8 +153,54 @@ def test_large_empty_cubes_and_run_ahead(vra, ora):
             want = ora.render_frame(f, low=scene.low, target=scene.target, planes=ALL, threads=16)
             got = gpu.render(f, planes=ALL)
             assert_planes_equal({p: v[0] for p, v in got.items()}, want, f"camera {i} naive={naive}")
+            assert_planes_equal({p: v[0] for p, v in gpu.render(f).items()}, want, f"camera {i} naive={naive}, five planes")
             total_hits += int((want["hit_index"] != MISS).sum())
             longest = max(longest, int(want["steps_hi"].max() if naive else want["steps_lo"].max()))
     assert total_hits > 500 and longest > 200
     gpu.close()
     scene.close()
+
+
+def test_sky_rectangle_is_safe_and_not_vacuous(vra, ora, teapot64, sphere64):
+    """volly_gpu_sky_rect: outside the rectangle the ORACLE must report a miss with zero steps in both
+    passes for every pixel (that is what culled tiles write without tracing); from outside the volume
+    the rectangle must actually exclude a good part of the frame; from inside, for raytrace frames and
+    for frames whose low and target constants disagree it must be the whole frame."""
+    rng = np.random.default_rng(11)
+    hi, lo = (64,) * 3, (16,) * 3
+    gpu = vra.GpuScene.upload_dense(teapot64.target, teapot64.low)
+    culled = total = 0
+    for case in range(60):
+        naive = case % 3 == 0
+        pos = (0.5 + (rng.random(3) - 0.5) * rng.uniform(0.2, 6.0)).astype(np.float32)
+        at = rng.random(3).astype(np.float32)
+        up = (0, 0, -1) if abs((at - pos)[2]) < 0.9 * np.linalg.norm(at - pos) else (0, 1, 0)
+        view = vra.look_at(pos, 2 * pos - at, up)
+        w, h = int(rng.integers(16, 200)), int(rng.integers(16, 150))
+        f = vra.frame_from_camera(view, pos, hi, lo, w, h, naive=naive)
+        if case % 4 == 1 and w > 20 and h > 20:
+            f.x0, f.y0, f.tile_w, f.tile_h = 5, 7, w - 9, h - 11
+        x_lo, x_hi, y_lo, y_hi = gpu.sky_rect(f)
+        want = ora.render_frame(f, low=teapot64.low, target=teapot64.target)
+        inside = np.zeros((f.tile_h, f.tile_w), bool)
+        if x_lo <= x_hi and y_lo <= y_hi:
+            inside[y_lo:y_hi + 1, x_lo:x_hi + 1] = True
+        out = ~inside
+        assert (want["hit_index"][out] == MISS).all() and (want["steps_lo"][out] == 0).all() and (want["steps_hi"][out] == 0).all(), \
+            f"case {case}: a pixel outside the sky rectangle {x_lo, x_hi, y_lo, y_hi} is not sky"
+        assert np.isinf(want["depth"][out]).all() and (want["rgba8"][out] == 255).all()
+        assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, want, f"case {case}")
+        culled += int(out.sum()); total += out.size
+        if np.all((pos > 0.05) & (pos < 0.95)):           # camera inside the volume: corners behind it
+            assert (x_lo, x_hi, y_lo, y_hi) == (0, f.tile_w - 1, 0, f.tile_h - 1)
+    assert culled > 0.2 * total, (culled, total)
+    # raytrace frames and inconsistent constants: no cull
+    pos, view = vra.orbit_camera(3, 16, 3.0)
+    f = vra.frame_from_camera(view, pos, hi, lo, 96, 64, raytrace=True)
+    assert gpu.sky_rect(f) == (0, 95, 0, 63)
+    f = vra.frame_from_camera(view, pos, hi, lo, 96, 64)
+    assert gpu.sky_rect(f) != (0, 95, 0, 63)
+    f.xdiff_hi[0] = f.xdiff_hi[0] * 1.01 + 0.001          # the target constants no longer describe the low rays
+    assert gpu.sky_rect(f) == (0, 95, 0, 63)
+    assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, ora.render_frame(f, low=teapot64.low, target=teapot64.target), "inconsistent")
+    gpu.close()

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -33,7 +34,7 @@ thread_local std::string g_err;
 // host code never uses the array's name as an address, only what hipGetSymbolAddress returned for
 // the device in question (noalloc_scratch below).
 namespace {
-constexpr size_t kNoAllocDescBytes = 4096;                 // vk::kInlineFrames descriptors of 176 B, padded
+constexpr size_t kNoAllocDescBytes = 4096;                 // vk::kInlineFrames descriptors of 176 B and cull rectangles of 16 B, padded
 constexpr size_t kNoAllocCkptFloats = (size_t)8 << 20;     // 32 MiB of direction checkpoints: 6 * ceil(tile_w / 8) * tile_h floats per frame
 constexpr int kMaxDevices = 64;
 }
@@ -43,7 +44,7 @@ using namespace vimpl;
 
 namespace {
 constexpr int kFrameChunk = 32;     // frames per launch (bounds the checkpoint scratch)
-static_assert(sizeof(volly_frame_desc) * vk::kInlineFrames <= kNoAllocDescBytes, "descriptor part of the static scratch");
+static_assert((sizeof(volly_frame_desc) + sizeof(int4)) * vk::kInlineFrames <= kNoAllocDescBytes, "descriptor part of the static scratch");
 
 std::mutex g_scratch_mutex;
 void *g_scratch_ptr[kMaxDevices] = {};
@@ -177,6 +178,7 @@ int new_scene(int device, volly_gpu_scene **out)
     volly_gpu_scene *s = new (std::nothrow) volly_gpu_scene();
     if (!s) return fail(VOLLY_E_NOMEM, "host allocation failed");
     s->device = device;
+    if (const char *e = std::getenv("VOLLY_SKY_CULL")) s->sky_cull = std::atoi(e) != 0;      // 0: every tile sets its rays up (A/B runs)
     {   // set-up is where the static scratch of the entry point that allocates nothing is looked up
         // (once per device, with that device current); a failure is reported by that entry point only
         DeviceGuard g(device);
@@ -266,6 +268,108 @@ int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, in
     return VOLLY_OK;
 }
 
+// ---- sky tiles -----------------------------------------------------------------------------
+// The pixel rectangle of a frame outside of which every ray provably ends BOTH passes at its first
+// bounds test (main.cpp:126-135 on the first iteration: 0 steps, no hit, depth +inf, pixel 255,0,0,0),
+// so that the frame kernel can write those values without setting the ray up.
+//
+// The serial direction sum of pixel (x, y) is row0 + y*ydiff + x*xdiff up to rounding (at most
+// ~6000 additions of values below 4: under one pixel spacing in the worst case), so a box corner Q
+// is seen at the pixel (a/c, b/c) where Q - origin = a*xdiff + b*ydiff + c*row0, and it lies in front
+// of the camera iff c > 0.  With all eight corners of a box in front, every point of the box is a
+// convex combination of them with positive weights c_i, so its pixel lies in the corners' bounding
+// rectangle: a ray through a pixel outside that rectangle misses the box.  Boxes are the grids
+// widened by a margin (one cell beyond the reference's own (-1, size) test) and the rectangle by
+// kSkyPixelMargin pixels, which dwarf every rounding error of the reference's arithmetic for a point
+// within 10^6 cells; farther points are outside any grid anyway.  Every point the reference computes
+// lies on (or within rounding of) its ray or is not finite, and both kinds fail the bounds test.
+// In beam mode the target pass starts on the low ray (scale * ptEnd) and runs along the TARGET
+// direction sum: the two sets of frame constants must describe the same rays (checked here at the
+// sub-rectangle's corners; a caller's inconsistent constants simply switch the cull off).
+// Returns the rectangle relative to the sub-rectangle, inclusive; the whole sub-rectangle = no cull.
+constexpr double kSkyPixelMargin = 4.0, kSkyCellMargin = 1.0;
+
+struct SkyPass { double o[3], r0[3], xd[3], yd[3], size[3]; };
+
+static bool sky_project(const SkyPass &p, double &xmin, double &xmax, double &ymin, double &ymax)
+{
+    // inverse of M = [xd | yd | r0] by cofactors
+    const double *A = p.xd, *B = p.yd, *C = p.r0;
+    const double c0[3] = {B[1] * C[2] - B[2] * C[1], B[2] * C[0] - B[0] * C[2], B[0] * C[1] - B[1] * C[0]};   // B x C
+    const double c1[3] = {C[1] * A[2] - C[2] * A[1], C[2] * A[0] - C[0] * A[2], C[0] * A[1] - C[1] * A[0]};   // C x A
+    const double c2[3] = {A[1] * B[2] - A[2] * B[1], A[2] * B[0] - A[0] * B[2], A[0] * B[1] - A[1] * B[0]};   // A x B
+    const double det = A[0] * c0[0] + A[1] * c0[1] + A[2] * c0[2];
+    const double na = std::sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]), nb = std::sqrt(B[0] * B[0] + B[1] * B[1] + B[2] * B[2]),
+                 nc = std::sqrt(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
+    if (!std::isfinite(det) || !(std::fabs(det) > 1e-9 * na * nb * nc) || !(na > 0) || !(nb > 0) || !(nc > 0)) return false;
+    xmin = ymin = 1e300; xmax = ymax = -1e300;
+    for (int k = 0; k < 8; ++k) {
+        double v[3];
+        for (int a = 0; a < 3; ++a) v[a] = (((k >> a) & 1) ? p.size[a] + kSkyCellMargin : -1.0 - kSkyCellMargin) - p.o[a];
+        const double a_ = (c0[0] * v[0] + c0[1] * v[1] + c0[2] * v[2]) / det, b_ = (c1[0] * v[0] + c1[1] * v[1] + c1[2] * v[2]) / det,
+                     c_ = (c2[0] * v[0] + c2[1] * v[1] + c2[2] * v[2]) / det;
+        const double len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (!std::isfinite(a_) || !std::isfinite(b_) || !(c_ * nc > 1e-3 * len)) return false;   // a corner beside or behind the camera: no cull
+        xmin = std::min(xmin, a_ / c_); xmax = std::max(xmax, a_ / c_);
+        ymin = std::min(ymin, b_ / c_); ymax = std::max(ymax, b_ / c_);
+    }
+    return true;
+}
+
+static void sky_rect(const volly_gpu_scene *s, const volly_frame_desc &f, bool enabled, int32_t out[4])
+{
+    out[0] = 0; out[1] = f.tile_w - 1; out[2] = 0; out[3] = f.tile_h - 1;            // no cull
+    if (!enabled || (f.flags & VOLLY_FRAME_RAYTRACE)) return;
+    const bool naive = (f.flags & VOLLY_FRAME_NAIVE) != 0;
+    SkyPass hi{}, lo{};
+    for (int a = 0; a < 3; ++a) {
+        hi.o[a] = f.origin_hi[a]; hi.r0[a] = f.row0_hi[a]; hi.xd[a] = f.xdiff_hi[a]; hi.yd[a] = f.ydiff_hi[a];
+        lo.o[a] = f.origin_lo[a]; lo.r0[a] = f.row0_lo[a]; lo.xd[a] = f.xdiff_lo[a]; lo.yd[a] = f.ydiff_lo[a];
+    }
+    hi.size[0] = s->target.sx; hi.size[1] = s->target.sy; hi.size[2] = s->target.sz;
+    lo.size[0] = s->low.sx; lo.size[1] = s->low.sy; lo.size[2] = s->low.sz;
+    double x0, x1, y0, y1;
+    if (naive) {
+        if (!sky_project(hi, x0, x1, y0, y1)) return;
+    } else {
+        // the target pass runs from scale * (a point of the low ray) along the target direction sum: both
+        // sets of constants must give the same rays.  D_hi and scale * D_lo are linear in (x, y), so their
+        // difference is largest at a corner of the sub-rectangle.
+        double sc[3], worst = 0.0, far = 0.0;
+        for (int a = 0; a < 3; ++a) sc[a] = f.scale_lo_to_hi[a];
+        for (int k = 0; k < 4; ++k) {
+            const double x = f.x0 + ((k & 1) ? f.tile_w - 1 : 0), y = f.y0 + ((k & 2) ? f.tile_h - 1 : 0);
+            double dh[3], dl[3], nh = 0.0, e = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                dh[a] = hi.r0[a] + y * hi.yd[a] + x * hi.xd[a];
+                dl[a] = sc[a] * (lo.r0[a] + y * lo.yd[a] + x * lo.xd[a]);
+                nh += dh[a] * dh[a]; e += (dh[a] - dl[a]) * (dh[a] - dl[a]);
+            }
+            if (!(nh > 0.0) || !std::isfinite(nh) || !std::isfinite(e)) return;
+            worst = std::max(worst, std::sqrt(e / nh));
+        }
+        SkyPass hb = hi;                                   // the target rays as they are traced: from the scaled low origin
+        for (int a = 0; a < 3; ++a) {
+            hb.o[a] = sc[a] * lo.o[a];
+            const double d0 = std::fabs(-1.0 - hb.o[a]), d1 = std::fabs(hi.size[a] + 1.0 - hb.o[a]);
+            far += std::max(d0, d1) * std::max(d0, d1);
+        }
+        far = std::sqrt(far);
+        if (!std::isfinite(far) || !(3.0 * far * worst <= 0.25 * kSkyCellMargin)) return;     // constants disagree: no cull
+        double u0, u1, v0, v1;
+        if (!sky_project(lo, x0, x1, y0, y1) || !sky_project(hb, u0, u1, v0, v1)) return;
+        x0 = std::min(x0, u0); x1 = std::max(x1, u1); y0 = std::min(y0, v0); y1 = std::max(y1, v1);
+    }
+    // absolute pixels -> the sub-rectangle's, widened, clamped (an empty range culls everything)
+    const double lo_x = std::floor(x0 - kSkyPixelMargin) - f.x0, hi_x = std::ceil(x1 + kSkyPixelMargin) - f.x0;
+    const double lo_y = std::floor(y0 - kSkyPixelMargin) - f.y0, hi_y = std::ceil(y1 + kSkyPixelMargin) - f.y0;
+    if (!std::isfinite(lo_x) || !std::isfinite(hi_x) || !std::isfinite(lo_y) || !std::isfinite(hi_y)) return;
+    out[0] = (int32_t)std::min(std::max(lo_x, 0.0), (double)f.tile_w);
+    out[1] = (int32_t)std::max(std::min(hi_x, (double)f.tile_w - 1.0), -1.0);
+    out[2] = (int32_t)std::min(std::max(lo_y, 0.0), (double)f.tile_h);
+    out[3] = (int32_t)std::max(std::min(hi_y, (double)f.tile_h - 1.0), -1.0);
+}
+
 size_t checkpoint_floats(const volly_frame_desc &f, int n)
 {
     return (size_t)n * (size_t)((f.tile_w + vk::kCkpt - 1) / vk::kCkpt) * (size_t)f.tile_h * 6;
@@ -298,7 +402,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         }
         s->scratch_stream = stream;
         s->scratch_in_use = true;
-        if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, sizeof(volly_frame_desc) * kFrameChunk));
+        if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, (sizeof(volly_frame_desc) + sizeof(int4)) * kFrameChunk));   // descriptors, then cull rectangles
         if (need > s->ckpt_floats) {
             if (s->d_ckpt) { HIP_TRY(hipFree(s->d_ckpt)); s->d_ckpt = nullptr; s->ckpt_floats = 0; }
             HIP_TRY(hipMalloc((void **)&s->d_ckpt, need * sizeof(float)));
@@ -308,14 +412,23 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         d_ckpt = s->d_ckpt;
     } else if (n > vk::kInlineFrames || need > kNoAllocCkptFloats)
         return fail(VOLLY_E_ARG, "render: batch does not fit the static scratch");
+    // the cull rectangles sit behind the descriptors (kFrameChunk of them in the scene's scratch,
+    // kInlineFrames in the static scratch of the entry point that allocates nothing)
+    int4 *d_cull = (int4 *)(d_frames + (no_alloc ? vk::kInlineFrames : kFrameChunk));
+    const bool cull_ok = s->sky_cull && !outs->pt_end;       // ptEnd of a miss is the reference's arithmetic: no shortcut
     const dim3 pre_grid((unsigned)((th + 63) / 64), (unsigned)n, 6);
     if (n <= vk::kInlineFrames) {                         // descriptors as kernel arguments: no copy ahead of the pre-pass
         vk::FrameBatch batch;
         std::memcpy(batch.f, frames, sizeof(volly_frame_desc) * (size_t)n);
         std::memset(batch.f + n, 0, sizeof(volly_frame_desc) * (size_t)(vk::kInlineFrames - n));
-        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, n, d_frames, d_ckpt);
+        std::memset(batch.cull, 0, sizeof batch.cull);
+        for (int i = 0; i < n; ++i) sky_rect(s, frames[i], cull_ok, batch.cull[i]);
+        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, n, d_frames, d_cull, d_ckpt);
     } else {
+        int32_t rects[kFrameChunk][4];
+        for (int i = 0; i < n; ++i) sky_rect(s, frames[i], cull_ok, rects[i]);
         HIP_TRY(hipMemcpyAsync(d_frames, frames, sizeof(volly_frame_desc) * (size_t)n, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_cull, rects, sizeof(int4) * (size_t)n, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(vk::direction_checkpoints, pre_grid, dim3(64), 0, stream, d_frames, n, d_ckpt);
     }
     HIP_TRY(hipGetLastError());
@@ -380,13 +493,13 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
 #endif
     if (s->is_svo)
         hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
-                           d_ckpt, o);
+                           d_cull, d_ckpt, o);
     else if (any_raytrace)
         hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low,
-                           d_frames, d_ckpt, o);
+                           d_frames, d_cull, d_ckpt, o);
     else
         hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
-                           d_ckpt, o);
+                           d_cull, d_ckpt, o);
     HIP_TRY(hipGetLastError());
     if (e1) HIP_TRY(hipEventRecord(e1, stream));
     if (!no_alloc) {                                      // what a later call on another stream waits for
@@ -716,6 +829,13 @@ static int dda_loop_of(const vk::DenseDev &g)
 {
     if (!host_grid_is_regular(g)) return 3;               // trace_dense_checked
     return g.use_regions ? 1 : 2;                         // trace_dense_regular_asm : trace_dense_bricks_asm
+}
+
+int volly_gpu_sky_rect(const volly_gpu_scene *scene, const volly_frame_desc *frame, int32_t rect[4])
+{
+    if (!scene || !frame || !rect) return fail(VOLLY_E_ARG, "null argument");
+    sky_rect(scene, *frame, scene->sky_cull, rect);
+    return VOLLY_OK;
 }
 
 int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)

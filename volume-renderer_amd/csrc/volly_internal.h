@@ -64,6 +64,7 @@ struct volly_gpu_scene {
     hipStream_t scratch_stream = nullptr;   // the stream the last call queued its use of the scratch on
     hipEvent_t scratch_event = nullptr;     // orders a call on another stream behind it (render_chunk)
     bool scratch_in_use = false;
+    bool sky_cull = true;           // tiles whose rays provably miss both grids write their miss values without ray set-up
     void *d_planes = nullptr;       // staging of the synchronous entry point
     size_t plane_bytes = 0;
     hipStream_t s_render = nullptr, s_copy = nullptr;   // pinned-output path: render and copy-back overlap

@@ -1062,11 +1062,14 @@ direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames,
 // host-to-device copy ahead of the pre-pass (4 us + a launch gap per call).  The kernel also
 // leaves the descriptors in frames_out, where the frame kernel reads them.
 constexpr int kInlineFrames = 16;
-struct FrameBatch { volly_frame_desc f[kInlineFrames]; };
+// cull: per frame the pixel rectangle {x_lo, x_hi, y_lo, y_hi} (inclusive, relative to the sub-rectangle)
+// outside of which every ray provably misses both grids (host: sky_rect in volly_gpu.hip)
+struct FrameBatch { volly_frame_desc f[kInlineFrames]; int32_t cull[kInlineFrames][4]; };
 static_assert(sizeof(FrameBatch) <= 3072, "kernel arguments are limited to 4 KB");
 
 __global__ void __launch_bounds__(64)
-direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *__restrict__ frames_out, float *__restrict__ ckpt)
+direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *__restrict__ frames_out, int4 *__restrict__ cull_out,
+                             float *__restrict__ ckpt)
 {
     const int f = blockIdx.y;
     if (f >= n_frames) return;
@@ -1079,6 +1082,8 @@ direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *_
         const uint32_t *src = (const uint32_t *)(args + f);
         uint32_t *dst = (uint32_t *)(frames_out + f);
         for (unsigned w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+        const int32_t *c = (const int32_t *)(args + kInlineFrames) + 4 * f;
+        if (threadIdx.x == 0) cull_out[f] = make_int4(c[0], c[1], c[2], c[3]);
     }
     checkpoint_chain(args[f], f, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, ckpt);
 }
@@ -1208,7 +1213,7 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
 template <bool SVO, bool RAYTRACE = false>
 __global__ void __launch_bounds__(kFrameThreads) VK_FRAME_WAVES_ATTR
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
-              const float *__restrict__ ckpt, OutDev out)
+              const int4 *__restrict__ cull, const float *__restrict__ ckpt, OutDev out)
 {
     const int f = blockIdx.z;
     // uniform, read with scalar loads where it is used: a by-value copy keeps ~50 scalar registers
@@ -1220,8 +1225,17 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
     const int xrel = (int)blockIdx.x * kBlockW + wave * kTile + (lane & 7);
     const int yrel = (int)blockIdx.y * kBlockH + (lane >> 3);
     if ((xrel < fd.tile_w) & (yrel < fd.tile_h)) {       // eight 32-byte row segments per store instruction
-        const Ckpt k = load_checkpoint(ckpt, fd, f, xrel, yrel);
-        const PixelOut o = render_pixel<SVO, RAYTRACE>(target, svo, low, fd, k, xrel);
+        // Sky tiles: outside the frame's cull rectangle every ray is known to end both passes at its
+        // first bounds test (0 steps, no hit -- what PixelOut starts as), so the 288-instruction
+        // set-up of direction, rays and entry points is skipped.  Wave-uniform: the tile's corner.
+        const int4 rect = cull[f];
+        const int tx = (int)blockIdx.x * kBlockW + (VK_WAVE_BLOCK > 1 ? __builtin_amdgcn_readfirstlane(wave) * kTile : 0), ty = (int)blockIdx.y * kBlockH;
+        const bool sky = (tx + kTile - 1 < rect.x) | (tx > rect.y) | (ty + kBlockH - 1 < rect.z) | (ty > rect.w);
+        PixelOut o;
+        if (!sky) {
+            const Ckpt k = load_checkpoint(ckpt, fd, f, xrel, yrel);
+            o = render_pixel<SVO, RAYTRACE>(target, svo, low, fd, k, xrel);
+        }
         const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
         if (out.rgba8) out.rgba8[p] = o.rgba;
         if (out.hit_index) out.hit_index[p] = o.hit;

@@ -45,6 +45,7 @@ _sig = {
     "volly_gpu_read_low_voxels": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
     "volly_gpu_read_svo": (C.c_int, [_vp, _vp, _vp]),
     "volly_gpu_scene_info": (C.c_int64, [_vp, C.c_int]),
+    "volly_gpu_sky_rect": (C.c_int, [_vp, C.POINTER(FrameDesc), C.POINTER(C.c_int32)]),
     "volly_gpu_free": (None, [_vp]),
     "volly_gpu_last_error": (C.c_char_p, []),
     "volly_gpu_abi_version": (C.c_int, []),
@@ -164,6 +165,12 @@ class GpuScene:
 
     def info(self, what):
         return int(lib.volly_gpu_scene_info(self._h, what))
+
+    def sky_rect(self, frame):
+        """volly_gpu_sky_rect: (x_lo, x_hi, y_lo, y_hi), inclusive, relative to the frame's sub-rectangle."""
+        r = (C.c_int32 * 4)()
+        _check(lib.volly_gpu_sky_rect(self._h, C.byref(frame), r), "volly_gpu_sky_rect")
+        return tuple(r)
 
     def dda_loops(self):
         """Which traversal loops this scene's frames run (volly_gpu_scene_info 14 / 15)."""
