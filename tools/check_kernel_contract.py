@@ -6,8 +6,8 @@ assembly the compiler actually produced (hipcc -S --cuda-device-only, same flags
      statements and the compiler is not told, so no other instruction of the translation unit may
      touch m0 (indexed registers, LDS-direct, messages, spills through m0 would corrupt the step
      counts and the iteration cap);
-  2. occupancy: the live frame kernels -- render_frames<true,false> (octree) and <false,false>
-     (dense) -- stay at <= 64 vector and <= 96 scalar registers, i.e. 8 wavefronts per SIMD, and
+  2. occupancy: the live frame kernels -- render_frames<true,false,TW> (octree) and <false,false,TW>
+     (dense), TW = 8 and 32 -- stay at <= 64 vector and <= 96 scalar registers, i.e. 8 wavefronts per SIMD, and
      spill nothing.  The loops' nine temporaries are the fixed registers v47-v55 (declared as
      clobbers, so the compiler keeps nothing live in them across the loops); if its own allocation
      grew past v55 the kernel would still be correct, and this check says when it passes 64;
@@ -27,7 +27,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-I" + os.path.join(ROOT, "include")]
 OURS = (re.compile(r"^s_mov_b32 m0, 0$"), re.compile(r"^s_mov_b32 s\d+, m0$"), re.compile(r"^s_add_u32 m0, m0, 1$"),
         re.compile(r"^s_cmp_ge_u32 m0, s\d+$"), re.compile(r"^s_add_u32 s\d+, m0, \d+$"))
-LIVE = ("_ZN2vk13render_framesILb1ELb0EEE", "_ZN2vk13render_framesILb0ELb0EEE")
+LIVE = ("_ZN2vk13render_framesILb1ELb0ELi8EEE", "_ZN2vk13render_framesILb0ELb0ELi8EEE",       # beam frames: 8 x 8 tiles
+        "_ZN2vk13render_framesILb1ELb0ELi32EEE", "_ZN2vk13render_framesILb0ELb0ELi32EEE")     # naive-only launches: 32 x 2 tiles
 MAX_VGPR, MAX_SGPR = 64, 96
 
 

@@ -449,9 +449,14 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         s->events.emplace_back(e0, e1);
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    dim3 grid((unsigned)((tw + vk::kBlockW - 1) / vk::kBlockW), (unsigned)((th + vk::kBlockH - 1) / vk::kBlockH), (unsigned)n);
-    bool any_raytrace = false;
-    for (int i = 0; i < n; ++i) any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
+    bool any_raytrace = false, all_naive = true;
+    for (int i = 0; i < n; ++i) {
+        any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
+        all_naive &= (frames[i].flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE)) == VOLLY_FRAME_NAIVE;
+    }
+    // launches of naive frames only are bound by the output path: 32 x 2 tiles (128-byte row segments); else 8 x 8
+    const int tile_w = all_naive ? vk::kTileNaive : vk::kTileBeam, block_w = tile_w * VK_WAVE_BLOCK, block_h = 64 / tile_w;
+    dim3 grid((unsigned)((tw + block_w - 1) / block_w), (unsigned)((th + block_h - 1) / block_h), (unsigned)n);
 #if VK_EXPERIMENTAL
     if (s->requeue && !any_raytrace && !no_alloc) {
         const size_t n_px = (size_t)n * tw * th;
@@ -491,12 +496,18 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
                            s->low, d_frames, d_ckpt, o);
     } else
 #endif
-    if (s->is_svo)
+    if (s->is_svo && all_naive)
+        hipLaunchKernelGGL((vk::render_frames<true, false, vk::kTileNaive>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
+                           d_cull, d_ckpt, o);
+    else if (s->is_svo)
         hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
                            d_cull, d_ckpt, o);
     else if (any_raytrace)
         hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low,
                            d_frames, d_cull, d_ckpt, o);
+    else if (all_naive)
+        hipLaunchKernelGGL((vk::render_frames<false, false, vk::kTileNaive>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
+                           d_cull, d_ckpt, o);
     else
         hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
                            d_cull, d_ckpt, o);

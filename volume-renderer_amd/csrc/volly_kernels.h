@@ -95,8 +95,12 @@ namespace vk {
 
 constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
 constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pixels of a row (at most kCkpt - 1 adds per lane)
-constexpr int kBlockW = 8 * VK_WAVE_BLOCK;   // workgroup covers VK_WAVE_BLOCK tiles of 8 x 8 pixels side by side
-constexpr int kBlockH = 8;
+// The wavefront's tile in the frame kernel is TW x 64/TW pixels (template parameter of render_frames):
+// 8 x 8 for frames with a beam pass -- the most compact ray bundle, fewest attention steps -- and 32 x 2 for
+// launches of naive frames only, which are bound by the output path: 128-byte instead of 32-byte row
+// segments per store (0.64 -> 0.52 ms on the headline frames in naive mode, profiles/r02_ab/ab_tile_shapes.log;
+// in beam mode 16 x 4 is neutral and 32 x 2 is 5-12 % slower).
+constexpr int kTileBeam = 8, kTileNaive = 32;
 #ifdef VK_PROBE_WAVES            // measurement only: cap the resident wavefronts per SIMD through the register allocation
 #define VK_FRAME_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(VK_PROBE_WAVES, VK_PROBE_WAVES)))
 #else
@@ -1210,7 +1214,7 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
 // ---- the frame kernel: main.cpp:256-272 for every pixel of the sub-rectangle --
 // RAYTRACE: the instantiation that can also serve VOLLY_FRAME_RAYTRACE frames (dense targets);
 // it needs 96 VGPRs, so frames of the live path never run through it.
-template <bool SVO, bool RAYTRACE = false>
+template <bool SVO, bool RAYTRACE = false, int TW = kTileBeam>
 __global__ void __launch_bounds__(kFrameThreads) VK_FRAME_WAVES_ATTR
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
               const int4 *__restrict__ cull, const float *__restrict__ ckpt, OutDev out)
@@ -1219,18 +1223,19 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
     // uniform, read with scalar loads where it is used: a by-value copy keeps ~50 scalar registers
     // busy for the whole kernel, and measured 0.5-1 % slower (profiles/r01_ab/ab_tiles_per_wave_c2.log, "new" vs "base")
     const volly_frame_desc &fd = frames[f];
-    // a wavefront covers an 8x8 tile; workgroups stay in dispatch order (round-robin over the XCDs
+    // a wavefront covers a TW x 64/TW tile; workgroups stay in dispatch order (round-robin over the XCDs
     // balances sky and object tiles; an XCD-contiguous order measured 12-60 % slower)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int xrel = (int)blockIdx.x * kBlockW + wave * kTile + (lane & 7);
-    const int yrel = (int)blockIdx.y * kBlockH + (lane >> 3);
+    constexpr int kBlockW = TW * VK_WAVE_BLOCK, kBlockH = 64 / TW;       // workgroup covers VK_WAVE_BLOCK tiles side by side
+    const int xrel = (int)blockIdx.x * kBlockW + wave * TW + (lane & (TW - 1));
+    const int yrel = (int)blockIdx.y * kBlockH + (lane / TW);
     if ((xrel < fd.tile_w) & (yrel < fd.tile_h)) {       // eight 32-byte row segments per store instruction
         // Sky tiles: outside the frame's cull rectangle every ray is known to end both passes at its
         // first bounds test (0 steps, no hit -- what PixelOut starts as), so the 288-instruction
         // set-up of direction, rays and entry points is skipped.  Wave-uniform: the tile's corner.
         const int4 rect = cull[f];
-        const int tx = (int)blockIdx.x * kBlockW + (VK_WAVE_BLOCK > 1 ? __builtin_amdgcn_readfirstlane(wave) * kTile : 0), ty = (int)blockIdx.y * kBlockH;
-        const bool sky = (tx + kTile - 1 < rect.x) | (tx > rect.y) | (ty + kBlockH - 1 < rect.z) | (ty > rect.w);
+        const int tx = (int)blockIdx.x * kBlockW + (VK_WAVE_BLOCK > 1 ? __builtin_amdgcn_readfirstlane(wave) * TW : 0), ty = (int)blockIdx.y * kBlockH;
+        const bool sky = (tx + TW - 1 < rect.x) | (tx > rect.y) | (ty + kBlockH - 1 < rect.z) | (ty > rect.w);
         PixelOut o;
         if (!sky) {
             const Ckpt k = load_checkpoint(ckpt, fd, f, xrel, yrel);
