@@ -261,6 +261,9 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
  * describe the same rays.  x_lo > x_hi or y_lo > y_hi: nothing can be hit.  VOLLY_SKY_CULL=0 in the
  * environment at scene creation switches the shortcut off. */
 int volly_gpu_sky_rect(const volly_gpu_scene *scene, const volly_frame_desc *frame, int32_t rect[4]);
+/* The same computation from the two grids' sizes alone (host arithmetic only: needs no scene and no
+ * GPU, which lets a CPU test hold it against the oracle).  size_lo may be NULL for naive frames. */
+int volly_gpu_sky_rect_for(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc *frame, int32_t rect[4]);
 
 void        volly_gpu_free(volly_gpu_scene *scene);
 const char *volly_gpu_last_error(void);

@@ -316,7 +316,7 @@ static bool sky_project(const SkyPass &p, double &xmin, double &xmax, double &ym
     return true;
 }
 
-static void sky_rect(const volly_gpu_scene *s, const volly_frame_desc &f, bool enabled, int32_t out[4])
+static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc &f, bool enabled, int32_t out[4])
 {
     out[0] = 0; out[1] = f.tile_w - 1; out[2] = 0; out[3] = f.tile_h - 1;            // no cull
     if (!enabled || (f.flags & VOLLY_FRAME_RAYTRACE)) return;
@@ -326,8 +326,7 @@ static void sky_rect(const volly_gpu_scene *s, const volly_frame_desc &f, bool e
         hi.o[a] = f.origin_hi[a]; hi.r0[a] = f.row0_hi[a]; hi.xd[a] = f.xdiff_hi[a]; hi.yd[a] = f.ydiff_hi[a];
         lo.o[a] = f.origin_lo[a]; lo.r0[a] = f.row0_lo[a]; lo.xd[a] = f.xdiff_lo[a]; lo.yd[a] = f.ydiff_lo[a];
     }
-    hi.size[0] = s->target.sx; hi.size[1] = s->target.sy; hi.size[2] = s->target.sz;
-    lo.size[0] = s->low.sx; lo.size[1] = s->low.sy; lo.size[2] = s->low.sz;
+    for (int a = 0; a < 3; ++a) { hi.size[a] = size_hi[a]; lo.size[a] = size_lo[a]; }
     double x0, x1, y0, y1;
     if (naive) {
         if (!sky_project(hi, x0, x1, y0, y1)) return;
@@ -368,6 +367,12 @@ static void sky_rect(const volly_gpu_scene *s, const volly_frame_desc &f, bool e
     out[1] = (int32_t)std::max(std::min(hi_x, (double)f.tile_w - 1.0), -1.0);
     out[2] = (int32_t)std::min(std::max(lo_y, 0.0), (double)f.tile_h);
     out[3] = (int32_t)std::max(std::min(hi_y, (double)f.tile_h - 1.0), -1.0);
+}
+
+static void sky_rect(const volly_gpu_scene *s, const volly_frame_desc &f, bool enabled, int32_t out[4])
+{
+    const int32_t hi[3] = {s->target.sx, s->target.sy, s->target.sz}, lo[3] = {s->low.sx, s->low.sy, s->low.sz};
+    sky_rect_dims(hi, lo, f, enabled, out);
 }
 
 size_t checkpoint_floats(const volly_frame_desc &f, int n)
@@ -840,6 +845,15 @@ static int dda_loop_of(const vk::DenseDev &g)
 {
     if (!host_grid_is_regular(g)) return 3;               // trace_dense_checked
     return g.use_regions ? 1 : 2;                         // trace_dense_regular_asm : trace_dense_bricks_asm
+}
+
+int volly_gpu_sky_rect_for(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc *frame, int32_t rect[4])
+{
+    if (!size_hi || !frame || !rect) return fail(VOLLY_E_ARG, "null argument");
+    const int32_t none[3] = {1, 1, 1};
+    if (!size_lo && !(frame->flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE))) return fail(VOLLY_E_ARG, "a beam frame needs the low grid's size");
+    sky_rect_dims(size_hi, size_lo ? size_lo : none, *frame, true, rect);
+    return VOLLY_OK;
 }
 
 int volly_gpu_sky_rect(const volly_gpu_scene *scene, const volly_frame_desc *frame, int32_t rect[4])

@@ -46,6 +46,7 @@ _sig = {
     "volly_gpu_read_svo": (C.c_int, [_vp, _vp, _vp]),
     "volly_gpu_scene_info": (C.c_int64, [_vp, C.c_int]),
     "volly_gpu_sky_rect": (C.c_int, [_vp, C.POINTER(FrameDesc), C.POINTER(C.c_int32)]),
+    "volly_gpu_sky_rect_for": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(FrameDesc), C.POINTER(C.c_int32)]),
     "volly_gpu_free": (None, [_vp]),
     "volly_gpu_last_error": (C.c_char_p, []),
     "volly_gpu_abi_version": (C.c_int, []),
@@ -80,6 +81,15 @@ def _frames_array(frames):
     for i, f in enumerate(frames):
         arr[i] = f
     return arr, len(frames)
+
+
+def sky_rect_for(size_hi, size_lo, frame):
+    """volly_gpu_sky_rect_for: the sky rectangle of `frame` for grids of these sizes (host arithmetic, no GPU)."""
+    hi = (C.c_int32 * 3)(*size_hi)
+    lo = (C.c_int32 * 3)(*size_lo) if size_lo is not None else None
+    r = (C.c_int32 * 4)()
+    _check(lib.volly_gpu_sky_rect_for(hi, lo, C.byref(frame), r), "volly_gpu_sky_rect_for")
+    return tuple(r)
 
 
 def tricube(tri9, device=0):
