@@ -844,7 +844,7 @@ int volly_gpu_read_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t count
 static int dda_loop_of(const vk::DenseDev &g)
 {
     if (!host_grid_is_regular(g)) return 3;               // trace_dense_checked
-    return g.use_regions ? 1 : 2;                         // trace_dense_regular_asm : trace_dense_bricks_asm
+    return g.use_regions ? 1 : 2;                         // trace_dense_regions_whole_asm : trace_dense_bricks_whole_asm
 }
 
 int volly_gpu_sky_rect_for(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc *frame, int32_t rect[4])

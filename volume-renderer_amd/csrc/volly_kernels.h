@@ -2,14 +2,17 @@
 //
 // What the kernels compute is fixed by the reference (file:line cited at each
 // function); how they compute it is MI355X-first:
-//   * one ray per lane, one 64-lane wavefront per 8x8 pixel tile, one wavefront per
-//     workgroup: a wave retires as soon as its 64 rays are done (eight 32-byte row
-//     segments per store instruction; the L2 merges the neighbouring tiles' segments);
+//   * one ray per lane, one 64-lane wavefront per 8x8 pixel tile (32x2 for launches of naive
+//     frames only, which are bound by the output path), one wavefront per workgroup: a wave
+//     retires as soon as its 64 rays are done; tiles whose rays provably miss both grids
+//     write their miss values without setting a ray up (sky_rect, volly_gpu.hip);
 //   * the dense grids are traversed through a derived 1-bit occupancy structure
 //     (4x4x4-voxel bricks, one 64-bit word each) kept beside the reference's 8-byte
 //     voxels; the 8-byte Voxel (voxel.h:13-16) is fetched once, at the hit.  A
 //     lane keeps the current brick word in registers, so most DDA steps touch
-//     no memory at all;
+//     no memory at all; the traversal loops are assembly that nothing leaves (hits and grid
+//     exits are recorded under exec masks), a lane in empty space watches the largest empty
+//     aligned cube around it, and wavefronts deep inside such cubes run steps blind;
 //   * every float operation is the reference's, in the reference's order, unfused
 //     (the file is compiled with -ffp-contract=off): hit index, step counts, end
 //     point and depth are bit-identical to the CPU restatement;
@@ -93,7 +96,7 @@ static_assert(VK_WAVE_BLOCK >= 1, "wavefronts per workgroup");
 
 namespace vk {
 
-constexpr int kTile = 8;            // wavefront tile is kTile x kTile pixels
+constexpr int kTile = 8;            // tile edge of the experimental kernels (volly_refill.h, volly_requeue.h)
 constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pixels of a row (at most kCkpt - 1 adds per lane)
 // The wavefront's tile in the frame kernel is TW x 64/TW pixels (template parameter of render_frames):
 // 8 x 8 for frames with a beam pass -- the most compact ray bundle, fewest attention steps -- and 32 x 2 for
