@@ -359,6 +359,35 @@ def test_config3_noise1024_rays_of_the_4k_frame(vra, ora):
     gpu.close()
 
 
+def test_sparse_1024_dense_grid_takes_the_region_loop_to_its_field_limits(vra, ora):
+    """A 1024^3 dense target that is almost empty (device-generated noise, p = 2^-26: ~16 voxels): the
+    region loop with its empty cubes and run-ahead blocks on a grid whose packed cell uses all ten bits
+    per axis -- cells next to x, y, z = 0 and 1023, where `cell + ahead` wraps between fields."""
+    res = 1024
+    gpu = vra.GpuScene.noise(res, 3, 1 << 6)
+    assert gpu.info(9) == 1 and gpu.dda_loops() == "target asm-regions, low asm-regions"
+    vox = gpu.read_voxels(0, res ** 3).reshape(res, res, res, 8)
+    low = gpu.read_low_voxels().reshape(res // 4, res // 4, res // 4, 8)
+    assert 0 < int((vox[..., 3] > 0).sum()) < 200
+    t_desc, l_desc = vra.host.dense_desc(vox), vra.host.dense_desc(low)
+    longest = 0
+    for naive in (True, False):
+        for view, (x0, y0) in ((300, (1700, 900)), (1900, (2300, 1300)), (3500, (900, 400))):
+            full = vra.orbit_frames((view,), 4096, (res,) * 3, (res // 4,) * 3, 3840, 2160, radius=1.05, naive=naive)[0]
+            f = full.copy()
+            f.x0, f.y0, f.tile_w, f.tile_h = x0, y0, 192, 96
+            want = ora.render_frame(f, low=l_desc, target=t_desc, threads=16)
+            assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, want, f"sparse1024 naive={naive} view {view}")
+            longest = max(longest, int(want["steps_hi"].max()), int(want["steps_lo"].max()))
+    assert longest > 1000                                  # rays cross the whole grid
+    # along the grid's edges and faces: cells with coordinates 0 and 1023
+    for org, d in (((-3.0, 0.5, 0.5), (1, 0, 0)), ((1030.0, 1023.5, 1023.5), (-1, 0, 0)), ((0.5, 1023.5, -2.0), (0, 0, 1)), ((1023.5, 1030.0, 0.5), (0, -1, 0))):
+        f = _manual_frame(vra, 16, 8, d, (0.0, 1e-4, 2e-4) if d[0] else (1e-4, 0.0, 2e-4) if d[1] else (1e-4, 2e-4, 0.0), (2e-4, 1e-4, 1e-4), org)
+        want = ora.render_frame(f, low=l_desc, target=t_desc)
+        assert_planes_equal({k: v[0] for k, v in gpu.render(f).items()}, want, f"sparse1024 edge ray from {org}")
+    gpu.close()
+
+
 def test_config5_stratocaster1024_full_frame_from_a_device_built_scene(vra, ora):
     """BASELINE config 5: stratocaster.ply at 1024^3 (octree), 1920x1080 orbit views.  The GPU
     scene is built on the device (volume_gpu_voxelize); the oracle traverses the host pipeline's
