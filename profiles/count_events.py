@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 k = (C.c_ulonglong * 16)()
 mod.lib.volly_gpu_debug_counters(k, 0)
 names = ["waves in the loop", "wave-steps", "attention steps", "steps with a region change", "steps with a grid exit",
-         "steps with a lane in a region with voxels", "steps with a lane in a brick with voxels", "steps with a brick-word load", "steps with a hit"]
+         "steps with a lane in a region with voxels", "steps with a lane in a brick with voxels", "steps with a brick-word load", "steps with a hit", "run-ahead blocks (4 steps each)"]
 rays = nv * W * H
 print(f"config {a.config} {a.mode}: {rays} rays, {rays // 64} tiles, lane-steps {int(out.sum(dtype=torch.int64).item())}")
 ws = k[1]
