@@ -472,9 +472,6 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
 #endif
 #define VK_STR2(x) #x
 #define VK_STR(x) VK_STR2(x)
-#ifndef VK_MAGIC_FLOOR
-#define VK_MAGIC_FLOOR 1             // the region loop takes floor(p) and the cell from p + 1.5 * 2^23 rounded toward -infinity (below)
-#endif
 // advance_unit (main.cpp:149-153) on the sample point in v47-v49, for the loops below
 #define VK_ADVANCE_UNIT \
         "v_floor_f32 v53, v47\n\t" \
@@ -496,58 +493,13 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
         "v_add_f32 %[cx], v54, %[cx]\n\t" \
         "v_add_f32 %[cy], v55, %[cy]\n\t" \
         "v_add_f32 %[cz], v53, %[cz]\n\t"
-// The same without v_floor_f32 and v_cvt_i32_f32 (VK_MAGIC_FLOOR, tools/magic_floor.hip).  With the single-precision
-// rounding mode set to "toward -infinity" for three additions, t = p + M (M = 1.5 * 2^23 = 0x4b400000) is
-// floor(p) + M exactly whenever |p| < 2^22: the sum lies in [2^23, 2^24), where the floats are the integers.
-// Back in round-to-nearest, t - (M - h) = floor(p) + h exactly (and +0 when it is zero, as floor(p) + h is), so
-// floor + heaviside cost 2 x 3 of the cheapest vector instructions instead of 3 v_floor_f32 + 3 v_add_f32; and
-// the low mantissa bits of t hold floor(p) as an integer: bits(tx) + (bits(ty) << 10) + (bits(tz) << 20) - 0x4b400000
-// is the packed cell (the shifted copies of 0x4b400000 leave the 32 bits), which saves the three conversions.
-// floor and the reference's truncation differ for -1 < p < 0 only; such a lane's key shows an x, y or z of -1,
-// which no watch or region key has, so it is looked at, and the grid-exit block decides it from v_cvt_i32_f32.
-// t lives in v50-v52 and outlives the attention blocks; the operands %[gx..gz] hold M - h.  The steps that run
-// ahead need no cell: they keep v_floor_f32 (the two s_setreg cost them what the cheaper additions save).
-#define VK_T_FROM_P \
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\t" \
-        "v_add_f32 v50, 0x4b400000, v47\n\t" \
-        "v_add_f32 v51, 0x4b400000, v48\n\t" \
-        "v_add_f32 v52, 0x4b400000, v49\n\t" \
-        "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\t"
-#define VK_ADVANCE_FROM_T \
-        "v_sub_f32 v53, v50, %[gx]\n\t" \
-        "v_sub_f32 v54, v51, %[gy]\n\t" \
-        "v_sub_f32 v55, v52, %[gz]\n\t" \
-        "v_sub_f32 v53, v53, %[cx]\n\t" \
-        "v_sub_f32 v54, v54, %[cy]\n\t" \
-        "v_sub_f32 v55, v55, %[cz]\n\t" \
-        "v_mul_f32 v53, v53, %[ix]\n\t" \
-        "v_mul_f32 v54, v54, %[iy]\n\t" \
-        "v_mul_f32 v55, v55, %[iz]\n\t" \
-        "v_min3_f32 v53, v53, v54, v55\n\t" \
-        "v_mul_f32 v54, v53, %[dx]\n\t" \
-        "v_mul_f32 v55, v53, %[dy]\n\t" \
-        "v_mul_f32 v53, v53, %[dz]\n\t" \
-        "v_add_f32 %[cx], v54, %[cx]\n\t" \
-        "v_add_f32 %[cy], v55, %[cy]\n\t" \
-        "v_add_f32 %[cz], v53, %[cz]\n\t"
-#if VK_MAGIC_FLOOR
-#define VK_MF(x) x
-#define VK_CF(x)
-#define VK_REGION_ADVANCE VK_ADVANCE_FROM_T
-#define VK_REGION_ADVANCE_P VK_ADVANCE_UNIT
-#else
-#define VK_MF(x)
-#define VK_CF(x) x
-#define VK_REGION_ADVANCE VK_ADVANCE_UNIT
-#define VK_REGION_ADVANCE_P VK_ADVANCE_UNIT
-#endif
 // one more step without cell, key or test: the sample point, then the advance
 #define VK_BLIND_STEP \
         "s_add_u32 m0, m0, 1\n\t" \
         "v_add_f32 v47, %[cx], %[ex]\n\t" \
         "v_add_f32 v48, %[cy], %[ey]\n\t" \
         "v_add_f32 v49, %[cz], %[ez]\n\t" \
-        VK_REGION_ADVANCE_P
+        VK_ADVANCE_UNIT
 #if VK_RUN_AHEAD == 2
 #define VK_RUN_AHEAD_MORE VK_BLIND_STEP
 #elif VK_RUN_AHEAD == 3
@@ -577,15 +529,7 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
     h.steps = 0;
     h.index = VOLLY_MISS_INDEX;
     h.payload = VOLLY_MISS_INDEX;
-#if VK_MAGIC_FLOOR
-    // An entry point this far out (or inf / NaN) fails the first bounds test: no step, a miss.  Every sample point
-    // the loop itself sees is then within a cell of the grid (<= 1024 per axis), far inside the 2^22 that
-    // p + 1.5 * 2^23 needs to be exact.
-    if (!(fabsf(h.cx) < 2.0e6f && fabsf(h.cy) < 2.0e6f && fabsf(h.cz) < 2.0e6f)) return h;
-    const float gx = 12582912.0f - r.hx, gy = 12582912.0f - r.hy, gz = 12582912.0f - r.hz;   // M - heaviside, exact
-#else
     if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
-#endif
     const uint32_t cap = g.cap;
     const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz;
     const uint4 *occ2 = g.occ2x;
@@ -593,24 +537,17 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
     uint32_t steps = 0xFFFFFFFFu;                         // still live
     uint32_t hitc = 0xFFFFFFFFu;                          // packed cell of the hit
     uint64_t mask_e, mask_a, mask_b, mask_c;
-    // Scalar temporaries are the fixed registers s64 (scratch) and s65 (`tr`, below); v61 holds the packed-cell offset of
-    // VK_RUN_AHEAD cells along the ray's octant, +-VK_RUN_AHEAD per field by the direction's sign bit (the rays here
-    // have no zero component).  Fields wrap: a field that leaves [0, 1024) changes its own high bits, so the masked
-    // compare fails, which is the safe answer.  Fixed registers cost none of the 30 operands a statement may have.
+    uint32_t tmp, tr;
+    // the packed-cell offset of VK_RUN_AHEAD cells along the ray's octant (fields wrap: a field that leaves
+    // [0, 1024) changes its own high bits, so the masked compare fails, which is the safe answer)
+    const uint32_t k_ahead = (uint32_t)VK_RUN_AHEAD;
+    const uint32_t ahead = (r.dx < 0.0f ? 0u - k_ahead : k_ahead) + ((r.dy < 0.0f ? 0u - k_ahead : k_ahead) << 10) +
+                           ((r.dz < 0.0f ? 0u - k_ahead : k_ahead) << 20);
     asm volatile(
         "s_mov_b64 %[se], exec\n\t"
         VK_CNT("s_mov_b32 s88, 0\n\ts_mov_b32 s89, 0\n\ts_mov_b32 s90, 0\n\ts_mov_b32 s91, 0\n\ts_mov_b32 s92, 0\n\ts_mov_b32 s93, 0\n\ts_mov_b32 s94, 0\n\ts_mov_b32 s95, 0\n\t")
         "s_mov_b32 m0, 0\n\t"
-        "s_mov_b32 s65, 1\n\t"
-        "v_ashrrev_i32 v53, 31, %[dx]\n\t"           // -1 / 0
-        "v_ashrrev_i32 v54, 31, %[dy]\n\t"
-        "v_ashrrev_i32 v55, 31, %[dz]\n\t"
-        "v_lshl_or_b32 v53, v53, 1, 1\n\t"           // -1 / +1
-        "v_lshl_or_b32 v54, v54, 1, 1\n\t"
-        "v_lshl_or_b32 v55, v55, 1, 1\n\t"
-        "v_lshl_add_u32 v61, v54, 10, v53\n\t"
-        "v_lshl_add_u32 v61, v55, 20, v61\n\t"
-        "v_mul_lo_u32 v61, v61, " VK_STR(VK_RUN_AHEAD) "\n\t"
+        "s_mov_b32 %[tr], 1\n\t"
         "v_mov_b32 v57, -1\n\t"                       // no region yet
         "v_mov_b32 v58, 0\n\t"
         "v_mov_b32 v59, 0\n\t"
@@ -623,15 +560,11 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         "v_add_f32 v47, %[cx], %[ex]\n\t"
         "v_add_f32 v48, %[cy], %[ey]\n\t"
         "v_add_f32 v49, %[cz], %[ez]\n\t"
-        VK_CF("v_cvt_i32_f32 v50, v47\n\t"
-              "v_cvt_i32_f32 v51, v48\n\t"
-              "v_cvt_i32_f32 v52, v49\n\t"
-              "v_lshl_or_b32 v56, v51, 10, v50\n\t"
-              "v_lshl_or_b32 v56, v52, 20, v56\n\t")
-        VK_MF(VK_T_FROM_P
-              "v_lshl_add_u32 v56, v51, 10, v50\n\t"
-              "v_lshl_add_u32 v56, v52, 20, v56\n\t"
-              "v_add_u32 v56, 0xb4c00000, v56\n\t")   // - 0x4b400000: the packed cell of floor(p)
+        "v_cvt_i32_f32 v50, v47\n\t"
+        "v_cvt_i32_f32 v51, v48\n\t"
+        "v_cvt_i32_f32 v52, v49\n\t"
+        "v_lshl_or_b32 v56, v51, 10, v50\n\t"
+        "v_lshl_or_b32 v56, v52, 20, v56\n\t"
         "v_and_b32 v53, v63, v56\n\t"
         "v_cmp_ne_u32 vcc, v53, v62\n\t"
         "s_cbranch_vccnz 3f\n\t"
@@ -642,25 +575,25 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         // every coordinate by at most one cell, always in the ray's direction) still lies in its empty cube, the
         // next VK_RUN_AHEAD steps can hit nothing and cannot leave the grid: they run without cell, key or test.
         // `tr` remembers whether the last such test passed; any attention step re-arms it.
-        "s_cmp_eq_u32 s65, 0\n\t"
+        "s_cmp_eq_u32 %[tr], 0\n\t"
         "s_cbranch_scc1 2f\n\t"
-        "v_add_u32 v53, v56, v61\n\t"
+        "v_add_u32 v53, v56, %[ahead]\n\t"
         "v_and_b32 v53, v63, v53\n\t"
         "v_cmp_ne_u32 vcc, v53, v62\n\t"
         "s_cbranch_vccnz 8f\n\t"
-        "s_add_u32 s64, m0, " VK_STR(VK_RUN_AHEAD) "\n\t"
-        "s_cmp_gt_u32 s64, %[cap]\n\t"
+        "s_add_u32 %[tmp], m0, " VK_STR(VK_RUN_AHEAD) "\n\t"
+        "s_cmp_gt_u32 %[tmp], %[cap]\n\t"
         "s_cbranch_scc1 2f\n\t"
         VK_CNT("s_add_u32 s95, s95, 1\n\t")
-        VK_REGION_ADVANCE
+        VK_ADVANCE_UNIT
         VK_RUN_AHEAD_MORE
         "s_add_u32 m0, m0, 1\n\t"
         "s_branch 1b\n"
         "8:\n\t"
-        "s_mov_b32 s65, 0\n"
+        "s_mov_b32 %[tr], 0\n"
 #endif
         "2:\n\t"                                      // ---- advance_unit (main.cpp:149-153), every live lane
-        VK_REGION_ADVANCE
+        VK_ADVANCE_UNIT
         "s_add_u32 m0, m0, 1\n\t"
         "s_branch 1b\n"
         "3:\n\t"                                      // ---- vcc = the lanes that are not quiet
@@ -674,63 +607,6 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         "s_and_saveexec_b64 %[sb], vcc\n\t"           // sb: the lanes to look at; exec: those in a new region
         "s_cbranch_execz 5f\n\t"
         VK_CNT("s_add_u32 s89, s89, 1\n\t")
-#if VK_MAGIC_FLOOR
-        "v_add_u32 v53, 0xb4c00000, v50\n\t"          // floor(p) as integers, from the bits of t
-        "v_add_u32 v54, 0xb4c00000, v51\n\t"
-        "v_add_u32 v55, 0xb4c00000, v52\n\t"
-        "v_cmp_gt_u32 vcc, %[sx], v53\n\t"
-        "v_cmp_gt_u32 %[sc], %[sy], v54\n\t"
-        "s_and_b64 vcc, vcc, %[sc]\n\t"
-        "v_cmp_gt_u32 %[sc], %[sz], v55\n\t"
-        "s_and_b64 vcc, vcc, %[sc]\n\t"               // vcc: floor(p) inside the grid (then it is the reference's cell)
-        "s_xor_b64 %[sc], exec, vcc\n\t"              // sc: floor(p) outside the grid
-        "s_cbranch_scc0 4f\n\t"
-        // ---- lanes with floor(p) outside the grid.  The reference truncates (main.cpp:126-135): a coordinate in (-1, 0)
-        // is cell 0.  Their cell comes from the conversions; those that are inside after all get their packed cell
-        // rewritten and are looked at like the others, the rest have left the grid.
-        "s_mov_b64 exec, %[sc]\n\t"
-        VK_CNT("s_add_u32 s90, s90, 1\n\t")
-        "v_cvt_i32_f32 v53, v47\n\t"
-        "v_cvt_i32_f32 v54, v48\n\t"
-        "v_cvt_i32_f32 v55, v49\n\t"
-        "v_cmp_gt_u32 vcc, %[sx], v53\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
-        "v_cmp_gt_u32 vcc, %[sy], v54\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
-        "v_cmp_gt_u32 vcc, %[sz], v55\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"               // exec: inside by truncation
-        "v_lshl_or_b32 v56, v54, 10, v53\n\t"
-        "v_lshl_or_b32 v56, v55, 20, v56\n\t"
-        "s_andn2_b64 %[sc], %[sc], exec\n\t"          // sc: lanes that left the grid
-        "s_mov_b64 exec, %[sc]\n\t"
-        "s_mov_b32 s64, m0\n\t"
-        "v_mov_b32 %[steps], s64\n\t"
-        "s_andn2_b64 %[sa], %[sa], %[sc]\n\t"         // no longer live
-        "s_andn2_b64 %[sb], %[sb], %[sc]\n\t"         // nor to be looked at
-        "s_mov_b64 exec, %[sb]\n\t"
-        "s_cbranch_execz 7f\n\t"
-        "v_and_b32 v53, 0xff0fc3f0, v56\n\t"          // who is in a new region, once more: all of them inside now
-        "v_cmp_ne_u32 vcc, v53, v57\n\t"
-        "s_and_b64 vcc, exec, vcc\n\t"
-        "s_cbranch_scc0 5f\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_and_b32 v53, 0x3ff, v56\n\t"
-        "v_bfe_u32 v54, v56, 10, 10\n\t"
-        "v_lshrrev_b32 v55, 20, v56\n"
-        "4:\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "s_cbranch_execz 5f\n\t"
-        "v_lshrrev_b32 v55, 4, v55\n\t"               // byte offset of the region entry: 16 * (x>>4 + nrx * (y>>4 + nry * (z>>4)))
-        "v_and_b32 v54, 0xfffffff0, v54\n\t"
-        "v_mad_u32_u24 v55, v55, %[sy], v54\n\t"      // 16 * (y>>4 + nry * (z>>4))
-        "v_mul_u32_u24 v55, v55, %[sx]\n\t"           // 256 * nrx * (...)
-        "v_lshrrev_b32 v55, 4, v55\n\t"
-        "v_lshrrev_b32 v53, 4, v53\n\t"
-        "v_lshl_add_u32 v55, v53, 4, v55\n\t"
-        "global_load_dwordx3 v[58:60], v55, %[occ2]\n\t"   // region word, and the key mask of the empty cube around an empty region
-        "v_and_b32 v57, 0xff0fc3f0, v56\n\t"
-        "s_waitcnt vmcnt(0)\n"
-#else
         "v_cmp_gt_u32 vcc, %[sx], v50\n\t"
         "v_cmp_gt_u32 %[sc], %[sy], v51\n\t"
         "s_and_b64 vcc, vcc, %[sc]\n\t"
@@ -740,10 +616,10 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         "s_cbranch_scc0 4f\n\t"
         "s_mov_b64 exec, %[sc]\n\t"                   // ---- lanes leaving the grid: main.cpp:126-135
         VK_CNT("s_add_u32 s90, s90, 1\n\t")
-        "s_mov_b32 s64, m0\n\t"
-        "v_mov_b32 %[steps], s64\n\t"
+        "s_mov_b32 %[tmp], m0\n\t"
+        "v_mov_b32 %[steps], %[tmp]\n\t"
         "s_andn2_b64 %[sa], %[sa], %[sc]\n\t"         // no longer live
-        "s_andn2_b64 %[sb], %[sb], %[sc]\n"            // nor to be looked at
+        "s_andn2_b64 %[sb], %[sb], %[sc]\n"           // nor to be looked at
         "4:\n\t"
         "s_mov_b64 exec, vcc\n\t"
         "s_cbranch_execz 5f\n\t"
@@ -754,10 +630,9 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         "v_lshrrev_b32 v54, 4, v54\n\t"
         "v_lshrrev_b32 v55, 4, v50\n\t"
         "v_lshl_add_u32 v54, v55, 4, v54\n\t"
-        "global_load_dwordx3 v[58:60], v54, %[occ2]\n\t"   // region word, and the key mask of the empty cube around an empty region
+        "global_load_dwordx4 v[58:61], v54, %[occ2]\n\t"   // region word, and the key mask of the empty cube around an empty region
         "v_mov_b32 v57, v53\n\t"
         "s_waitcnt vmcnt(0)\n"
-#endif
         "5:\n\t"
         "s_mov_b64 exec, %[sb]\n\t"                   // the lanes to look at, all inside the grid
         "s_cbranch_execz 7f\n\t"
@@ -790,19 +665,12 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         "s_and_saveexec_b64 %[sc], vcc\n\t"           // sc: lanes in such a brick; exec: those that need its word
         "s_cbranch_execz 6f\n\t"
         VK_CNT("s_add_u32 s93, s93, 1\n\t")
-        VK_CF("v_lshrrev_b32 v54, 2, v52\n\t"         // byte offset of the brick word: 8 * (x>>2 + nbx * (y>>2 + nby * (z>>2)))
-              "v_and_b32 v55, 0xfffffffc, v51\n\t"
-              "v_mad_u32_u24 v54, v54, %[sy], v55\n\t"      // 4 * (y>>2 + nby * (z>>2))
-              "v_mul_u32_u24 v54, v54, %[sx]\n\t"           // 16 * nbx * (...)
-              "v_lshrrev_b32 v54, 1, v54\n\t"
-              "v_lshrrev_b32 v55, 2, v50\n\t")
-        VK_MF("v_lshrrev_b32 v54, 22, v56\n\t"        // the same from the packed cell (v50-v52 hold t): z>>2,
-              "v_bfe_u32 v55, v56, 12, 8\n\t"         // y>>2,
-              "s_lshr_b32 s64, %[sy], 2\n\t"
-              "v_mad_u32_u24 v54, v54, s64, v55\n\t"     // y>>2 + nby * (z>>2)
-              "v_mul_u32_u24 v54, v54, %[sx]\n\t"           // 4 * nbx * (...)
-              "v_lshlrev_b32 v54, 1, v54\n\t"
-              "v_bfe_u32 v55, v56, 2, 8\n\t")         // x>>2
+        "v_lshrrev_b32 v54, 2, v52\n\t"               // byte offset of the brick word: 8 * (x>>2 + nbx * (y>>2 + nby * (z>>2)))
+        "v_and_b32 v55, 0xfffffffc, v51\n\t"
+        "v_mad_u32_u24 v54, v54, %[sy], v55\n\t"      // 4 * (y>>2 + nby * (z>>2))
+        "v_mul_u32_u24 v54, v54, %[sx]\n\t"           // 16 * nbx * (...)
+        "v_lshrrev_b32 v54, 1, v54\n\t"
+        "v_lshrrev_b32 v55, 2, v50\n\t"
         "v_lshl_add_u32 v54, v55, 3, v54\n\t"
         "global_load_dwordx2 v[44:45], v54, %[occ]\n\t"
         "v_mov_b32 v46, v53\n\t"
@@ -818,25 +686,22 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
         "s_cbranch_vccz 7f\n\t"
         "s_mov_b64 exec, vcc\n\t"                     // ---- hits: main.cpp:139-142
         VK_CNT("s_add_u32 s94, s94, 1\n\t")
-        "s_add_u32 s64, m0, 1\n\t"
-        "v_mov_b32 %[steps], s64\n\t"
+        "s_add_u32 %[tmp], m0, 1\n\t"
+        "v_mov_b32 %[steps], %[tmp]\n\t"
         "v_mov_b32 %[hitc], v56\n\t"
         "s_andn2_b64 %[sa], %[sa], vcc\n"
         "7:\n\t"
-        "s_mov_b32 s65, 1\n\t"
+        "s_mov_b32 %[tr], 1\n\t"
         "s_mov_b64 exec, %[sa]\n\t"
         "s_cbranch_execnz 2b\n"                       // the step itself, for the lanes still live
         "9:\n\t"
         "s_mov_b64 exec, %[se]"
         : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [steps] "+v"(steps), [hitc] "+v"(hitc),
-          [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sb] "=&s"(mask_b), [sc] "=&s"(mask_c)
+          [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sb] "=&s"(mask_b), [sc] "=&s"(mask_c), [tmp] "=&s"(tmp), [tr] "=&s"(tr)
         : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
           [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-#if VK_MAGIC_FLOOR
-          [gx] "v"(gx), [gy] "v"(gy), [gz] "v"(gz),
-#endif
-          [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [occ2] "s"(occ2), [occ] "s"(occ)
-        : "vcc", "scc", "memory", "s64", "s65", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+          [ahead] "v"(ahead), [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [occ2] "s"(occ2), [occ] "s"(occ)
+        : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
           "v60", "v61", "v62", "v63"
 #if VK_COUNT
           , "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
