@@ -61,6 +61,10 @@ tools/exhaustive_math: tools/exhaustive_math.hip
 # issue rate of the instruction kinds the DDA loop is made of
 tools/valu_rate: tools/valu_rate.hip
 	$(HIPCC) --offload-arch=gfx950 -O3 -Wno-unused-result -o $@ $<
+# floor(p) + h and the packed cell from p + 1.5 * 2^23 rounded toward -infinity: exactness and step cost
+tools/_bin/magic_floor: tools/magic_floor.hip
+	@mkdir -p tools/_bin
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 $(FPFLAGS) -Wno-unused-result -o $@ $<
 
 # alternative builds of the kernels for A/B measurement (profiles/ab_bench.py); never loaded by the product
 # `experimental` also holds the two frame kernels round 1 measured and did not adopt (volly_refill.h,
