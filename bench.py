@@ -7,10 +7,11 @@ Default workload (--config 0) is BASELINE.json's north-star target: dragon.off v
 1024^3, octree target, 256^3 beam grid, 3840x2160 frames, the reference's live per-pixel call
 (raycast_beamOpt, main.cpp:260 -> main.cpp:163-166).  --config 1..5 are BASELINE.json's configs.
 
-One "step" = one pass of the hot path over one batch of `--views` orbit views on every rank
-(weak scaling: per-GPU work is fixed, views are dealt round-robin to the ranks, scene replicated,
-no collective on the data path; --config 4 / --split is the single-frame row-band split with one
-gather).  Inputs (octree, low grid) are resident in HBM before the timed region; outputs (rgba8,
+One "step" = one pass of the hot path over one batch of `--views` orbit views on every rank,
+one launch of the frame kernel per rank for up to 64 views (16 x 4K = 133 M rays by default: launches
+of this size run at the kernel's steady rate).  Weak scaling: per-GPU work is
+fixed, views are dealt round-robin to the ranks, scene replicated, no collective on the data path
+(--config 4 / --split is the single-frame row-band split with one gather).  Inputs (octree, low grid) are resident in HBM before the timed region; outputs (rgba8,
 hit index, step counts, depth: 20 B/ray) stay in HBM.  Rank 0 prints ONE JSON line.
 
 --gpus N > 1 without a launcher (no WORLD_SIZE in the environment): this process starts N ranks
@@ -35,12 +36,12 @@ PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r02.json")   # written by profile
 
 # workload parameters (scene "noise" = volume_gpu_generate_noise; several scenes = alternate per step)
 PRESETS = {
-    0: dict(scene="dragon.off", res=1024, target="svo", width=3840, height=2160, views=4, radius=1.0, split=False),   # north-star target
+    0: dict(scene="dragon.off", res=1024, target="svo", width=3840, height=2160, views=16, radius=1.0, split=False),  # north-star target
     1: dict(scene="teapot.off", res=128, target="svo", width=640, height=480, views=64, radius=1.0, split=False),
-    2: dict(scene="dragon.off", res=512, target="svo", width=1920, height=1080, views=16, radius=1.0, split=False),
+    2: dict(scene="dragon.off", res=512, target="svo", width=1920, height=1080, views=64, radius=1.0, split=False),
     3: dict(scene="noise", res=1024, target="dense", width=3840, height=2160, views=2, radius=1.1, split=False),
     4: dict(scene="galleon.ply", res=2048, target="svo", width=7680, height=4320, views=1, radius=1.0, split=True),
-    5: dict(scene="stratocaster.ply,dragon.off", res=1024, target="svo", width=1920, height=1080, views=16, radius=1.2, split=False),
+    5: dict(scene="stratocaster.ply,dragon.off", res=1024, target="svo", width=1920, height=1080, views=64, radius=1.2, split=False),
 }
 
 
@@ -228,12 +229,18 @@ def main():
     ptrs = {p: t.data_ptr() for p, t in planes.items()}
     stream = torch.cuda.current_stream(dev)
 
+    # Weak scaling wants the same work per rank at every N.  Work per view changes along the orbit, so the
+    # north-star workload samples the orbit `world` times finer at `world` ranks: the job's K steps then cover
+    # the same arc at every N (views j of a 4096 * world orbit, dealt round-robin), and each rank's views span
+    # it evenly.  Configs 1-5 keep SURVEY 8d's 4096-view orbit.
+    orbit_n = ORBIT_VIEWS * world if (args.config == 0 and not split) else ORBIT_VIEWS
+
     def step_frames(step):
         if split:      # every rank renders its row band of the SAME view
             ks = [step % ORBIT_VIEWS]
         else:          # ranks interleave through the orbit: view k goes to rank k mod world
-            ks = [((step * B + i) * world + rank) % ORBIT_VIEWS for i in range(B)]
-        frames = vra.orbit_frames(ks, ORBIT_VIEWS, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
+            ks = [((step * B + i) * world + rank) % orbit_n for i in range(B)]
+        frames = vra.orbit_frames(ks, orbit_n, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
         if split:
             frames[0] = frames[0].band(y0, rows)
         return frames

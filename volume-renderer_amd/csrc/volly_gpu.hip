@@ -43,7 +43,7 @@ static __device__ __align__(256) unsigned char scratch[kNoAllocDescBytes + kNoAl
 using namespace vimpl;
 
 namespace {
-constexpr int kFrameChunk = 32;     // frames per launch (bounds the checkpoint scratch)
+constexpr int kFrameChunk = 64;     // most frames per launch (larger launches run closer to the kernel's steady rate: DESIGN.md section 5a)
 static_assert((sizeof(volly_frame_desc) + sizeof(int4)) * vk::kInlineFrames <= kNoAllocDescBytes, "descriptor part of the static scratch");
 
 std::mutex g_scratch_mutex;
@@ -421,20 +421,18 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     // kInlineFrames in the static scratch of the entry point that allocates nothing)
     int4 *d_cull = (int4 *)(d_frames + (no_alloc ? vk::kInlineFrames : kFrameChunk));
     const bool cull_ok = s->sky_cull && !outs->pt_end;       // ptEnd of a miss is the reference's arithmetic: no shortcut
-    const dim3 pre_grid((unsigned)((th + 63) / 64), (unsigned)n, 6);
-    if (n <= vk::kInlineFrames) {                         // descriptors as kernel arguments: no copy ahead of the pre-pass
+    // The descriptors travel as kernel arguments, kInlineFrames per pre-pass launch: no host-to-device copy (from
+    // pageable memory it would block the host and leave the queue empty between calls).  The pre-pass also leaves
+    // them, and the cull rectangles, in the scratch where the frame kernel reads them.
+    for (int base = 0; base < n; base += vk::kInlineFrames) {
+        const int nb = std::min(vk::kInlineFrames, n - base);
         vk::FrameBatch batch;
-        std::memcpy(batch.f, frames, sizeof(volly_frame_desc) * (size_t)n);
-        std::memset(batch.f + n, 0, sizeof(volly_frame_desc) * (size_t)(vk::kInlineFrames - n));
+        std::memcpy(batch.f, frames + base, sizeof(volly_frame_desc) * (size_t)nb);
+        std::memset(batch.f + nb, 0, sizeof(volly_frame_desc) * (size_t)(vk::kInlineFrames - nb));
         std::memset(batch.cull, 0, sizeof batch.cull);
-        for (int i = 0; i < n; ++i) sky_rect(s, frames[i], cull_ok, batch.cull[i]);
-        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, n, d_frames, d_cull, d_ckpt);
-    } else {
-        int32_t rects[kFrameChunk][4];
-        for (int i = 0; i < n; ++i) sky_rect(s, frames[i], cull_ok, rects[i]);
-        HIP_TRY(hipMemcpyAsync(d_frames, frames, sizeof(volly_frame_desc) * (size_t)n, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(d_cull, rects, sizeof(int4) * (size_t)n, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(vk::direction_checkpoints, pre_grid, dim3(64), 0, stream, d_frames, n, d_ckpt);
+        for (int i = 0; i < nb; ++i) sky_rect(s, frames[base + i], cull_ok, batch.cull[i]);
+        const dim3 pre_grid((unsigned)((th + 63) / 64), (unsigned)nb, 6);
+        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, nb, d_frames + base, d_cull + base, d_ckpt, base);
     }
     HIP_TRY(hipGetLastError());
 
@@ -653,8 +651,11 @@ int volume_gpu_render_device(volly_gpu_scene *scene, const volly_frame_desc *fra
     DeviceGuard g(scene->device);
     if (!g.ok) return fail(VOLLY_E_HIP, "hipSetDevice failed");
     hipStream_t stream = (hipStream_t)hip_stream;
-    for (int first = 0; first < n_frames; first += kFrameChunk) {
-        const int n = std::min(kFrameChunk, n_frames - first);
+    // one launch per chunk: up to kFrameChunk frames, fewer when their direction checkpoints would pass 2 GiB of scratch
+    const size_t per_frame = std::max<size_t>(checkpoint_floats(frames[0], 1), 1);
+    const int chunk = (int)std::min<size_t>((size_t)kFrameChunk, std::max<size_t>(((size_t)1 << 29) / per_frame, 1));
+    for (int first = 0; first < n_frames; first += chunk) {
+        const int n = std::min(chunk, n_frames - first);
         if ((rc = render_chunk(scene, frames + first, n, (size_t)first, outs, stream))) return rc;
     }
     return VOLLY_OK;

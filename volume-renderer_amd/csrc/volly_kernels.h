@@ -1058,26 +1058,21 @@ __device__ __forceinline__ void checkpoint_chain(const volly_frame_desc &fd, int
     }
 }
 
-__global__ void __launch_bounds__(64)
-direction_checkpoints(const volly_frame_desc *__restrict__ frames, int n_frames, float *__restrict__ ckpt)
-{
-    const int f = blockIdx.y;
-    if (f >= n_frames) return;
-    checkpoint_chain(frames[f], f, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, ckpt);
-}
-
-// The same with the frame descriptors of a small batch travelling as kernel arguments: no
-// host-to-device copy ahead of the pre-pass (4 us + a launch gap per call).  The kernel also
-// leaves the descriptors in frames_out, where the frame kernel reads them.
+// The pre-pass kernel.  The frame descriptors of a batch travel as kernel arguments: no
+// host-to-device copy ahead of the pre-pass (4 us + a launch gap per call, and a blocked host
+// when the caller's array is pageable).  The kernel also leaves the descriptors in frames_out,
+// where the frame kernel reads them.
 constexpr int kInlineFrames = 16;
 // cull: per frame the pixel rectangle {x_lo, x_hi, y_lo, y_hi} (inclusive, relative to the sub-rectangle)
 // outside of which every ray provably misses both grids (host: sky_rect in volly_gpu.hip)
 struct FrameBatch { volly_frame_desc f[kInlineFrames]; int32_t cull[kInlineFrames][4]; };
 static_assert(sizeof(FrameBatch) <= 3072, "kernel arguments are limited to 4 KB");
 
+// base: index of the batch's first frame in the launch (a launch of more than kInlineFrames frames takes one
+// pre-pass per kInlineFrames of them; frames_out and cull_out point at the batch's first entry).
 __global__ void __launch_bounds__(64)
 direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *__restrict__ frames_out, int4 *__restrict__ cull_out,
-                             float *__restrict__ ckpt)
+                             float *__restrict__ ckpt, int base)
 {
     const int f = blockIdx.y;
     if (f >= n_frames) return;
@@ -1093,7 +1088,7 @@ direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *_
         const int32_t *c = (const int32_t *)(args + kInlineFrames) + 4 * f;
         if (threadIdx.x == 0) cull_out[f] = make_int4(c[0], c[1], c[2], c[3]);
     }
-    checkpoint_chain(args[f], f, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, ckpt);
+    checkpoint_chain(args[f], base + f, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, ckpt);
 }
 
 // what one ray leaves behind (RaycastReport + the pixel, main.cpp:81-86,269-271)
