@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG/$KEY
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-device-prepare $*"
+ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-device-prepare $*"
 echo "$ARGS" > $OUT/bench_args.txt
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1 || { echo "$KEY: trace run failed"; tail -5 $OUT/trace.log; exit 1; }
 grep '^{' $OUT/trace.log > $OUT/bench_line.json
