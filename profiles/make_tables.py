@@ -2,10 +2,10 @@
 """Markdown tables of DESIGN.md section 5a from profiles/r02/bench_*.json and profiles/pmc_r02.json."""
 import json, os
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r02")
-rows = [("c0", "**headline**: dragon 1024³ octree, 4 × 4K, beam"), ("c0_naive", "headline, naive (pure octree traversal from the camera)"),
-        ("c1", "config 1: teapot 128³, 64 × 640×480"), ("c2", "config 2: dragon 512³, 16 × 1080p, beam"), ("c2_naive", "config 2, naive"),
+rows = [("c0", "**headline**: dragon 1024³ octree, 16 × 4K, beam"), ("c0_naive", "headline, naive (pure octree traversal from the camera)"),
+        ("c1", "config 1: teapot 128³, 64 × 640×480"), ("c2", "config 2: dragon 512³, 64 × 1080p, beam"), ("c2_naive", "config 2, naive"),
         ("c3", "config 3: noise 1024³ dense, 2 × 4K, p = 1/256"), ("c3_p64", "config 3, p = 1/64"), ("c3_p1024", "config 3, p = 1/1024"),
-        ("c4", "config 4: galleon 2048³ octree, one 8K frame, 1 GPU"), ("c5", "config 5: stratocaster / dragon 1024³ alternating, 16 × 1080p")]
+        ("c4", "config 4: galleon 2048³ octree, one 8K frame, 1 GPU"), ("c5", "config 5: stratocaster / dragon 1024³ alternating, 64 × 1080p")]
 print("| Workload | Mrays/s (1 GPU, wall) | ms per step | kernel ms / launch | steps per ray (low + target) | algorithmic GB/s (frac of 8 TB/s) | CPU oracle, 1 core |")
 print("|---|---|---|---|---|---|---|")
 for k, name in rows:
