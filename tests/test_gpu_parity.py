@@ -86,14 +86,22 @@ def test_row_bands_and_columns(vra, ora, teapot64, kind):
 
 
 def test_batch_crosses_launch_chunk(vra, ora, teapot64):
-    """More frames than one launch takes (32): frame-major output planes stay in order."""
+    """More frames than one pre-pass launch carries (16) and than one frame-kernel launch takes (64):
+    frame-major output planes stay in order, through the host-buffer and the device entry point."""
+    import torch
     hi, lo = _sizes(teapot64)
     gpu = vra.GpuScene.upload_svo(teapot64.svo, teapot64.low)
-    frames = vra.orbit_frames(range(70), 70, hi, lo, 48, 40, radius=0.9)
-    got = gpu.render(frames, planes=("hit_index", "depth"))
-    for i in (0, 31, 32, 33, 63, 64, 69):
+    n = 140
+    frames = vra.orbit_frames(range(n), n, hi, lo, 48, 40, radius=0.9)
+    got = gpu.render(frames, planes=("hit_index", "depth", "steps_lo"))
+    for i in (0, 15, 16, 17, 31, 32, 47, 48, 63, 64, 65, 127, 128, 139):
         want = ora.render_frame(frames[i], low=teapot64.low, svo=teapot64.svo)
         assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"frame {i}")
+    dev = {p: torch.full((n, 40, 48), 7, dtype=torch.float32 if p == "depth" else torch.int32, device="cuda:0") for p in got}
+    gpu.render_device(frames, {p: t.data_ptr() for p, t in dev.items()})
+    torch.cuda.synchronize()
+    for p, t in dev.items():
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), np.asarray(got[p]).view(np.uint32)), p
     gpu.close()
 
 
