@@ -378,7 +378,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and scene is not None:
         from __graft_entry__ import load_oracle
         ora = load_oracle()
-        n_cpu = args.cpu_frames or max(1, min(8, int(round(16e6 / (W * H)))))
+        n_cpu = args.cpu_frames or max(1, min(B, int(round(40e6 / (W * H)))))      # ~40 M rays: 10-20 s of one core
         s0 = args.warmup + (-args.warmup) % len(gpus)          # a timed step that rendered names[0]
         frames = all_frames[s0 if s0 < len(all_frames) else args.warmup]
         kw = dict(low=scene.low, target=scene.target) if want_dense else dict(low=scene.low, svo=scene.svo)
