@@ -163,12 +163,12 @@ int volume_gpu_render_device(volly_gpu_scene *scene, const volly_frame_desc *fra
  * reference (which never allocates per frame: main.cpp:197-291 works in the locked texture); it is
  * for callers that cannot call hipMalloc: code under HIP graph capture, tight serving loops,
  * harnesses that forbid allocation.  Same arguments, same results bit for bit; it calls no
- * hipMalloc / hipFree / allocating library routine and takes its scratch (frame descriptors and
- * direction checkpoints) from a 32 MiB + 4 KiB array that lives in the library's device image --
- * each GPU the library runs on holds its copy until the process ends.
+ * hipMalloc / hipFree / allocating library routine and takes its scratch (frame descriptors, sky
+ * spans and direction checkpoints) from a 33 MiB + 4 KiB array that lives in the library's device
+ * image -- each GPU the library runs on holds its copy until the process ends.
  * Limit: one sub-rectangle's checkpoints, 6 * ceil(tile_w / 8) * tile_h floats, must fit 32 MiB
- * (up to ~11 Mpixel: a 3840x2160 frame fits, a 7680x4320 frame needs row bands of <= 1456 rows);
- * larger ones are rejected with VOLLY_E_ARG.  Any number of frames: they are rendered in launches
+ * (up to ~11 Mpixel: a 3840x2160 frame fits, a 7680x4320 frame needs row bands of <= 1456 rows),
+ * and tile_h <= 262144 (the spans' 1 MiB); larger ones are rejected with VOLLY_E_ARG.  Any number of frames: they are rendered in launches
  * of as many as fit.  Kernel timing (volly_gpu_set_profiling) is not recorded for these calls.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams,
  * threads or scenes) race; calls queued on one stream do not. */
@@ -265,6 +265,14 @@ int volly_gpu_sky_rect(const volly_gpu_scene *scene, const volly_frame_desc *fra
  * GPU, which lets a CPU test hold it against the oracle).  size_lo may be NULL for naive frames. */
 int volly_gpu_sky_rect_for(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc *frame, int32_t rect[4]);
 
+/* The spans the frame kernel culls with: for tile row r (rows r*block_h .. r*block_h+block_h-1 of the sub-rectangle;
+ * block_h = 8 for frames with a beam pass, 2 for launches of naive frames only) spans[2r], spans[2r+1] = the first
+ * and last column (relative to the sub-rectangle) that may hold a ray entering a grid; first > last: none.  They are
+ * the rectangle above cut by up to five edges of the projected boxes' convex hull (hull_out, optional: 5 x {a, b, c},
+ * a*X + b*Y + c <= 0 in absolute pixels; unused entries 0, 0, -1).  Host arithmetic -- the same function the
+ * pre-pass kernel runs per tile row.  No reference counterpart. */
+int volly_gpu_sky_spans_for(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc *frame, int32_t block_h,
+                            int32_t *spans, float *hull_out);
 void        volly_gpu_free(volly_gpu_scene *scene);
 const char *volly_gpu_last_error(void);
 int         volly_gpu_abi_version(void);

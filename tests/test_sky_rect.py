@@ -37,7 +37,7 @@ def test_pixels_outside_the_sky_rectangle_are_sky(vra, ora, seed):
     low = _low_of(vox, [4, 4, 8, 4, 2, 4][seed])
     scene = vra.HostScene.from_dense(vox, low, svo=False)
     hi = (shape[2], shape[1], shape[0]); lo = (low.shape[2], low.shape[1], low.shape[0])
-    culled = total = trivial = 0
+    culled = total = trivial = hull_culled = rect_area = 0
     for case in range(40):
         naive = case % 3 == 0
         pos = (0.5 + (rng.random(3) - 0.5) * rng.uniform(0.1, 8.0)).astype(np.float32)
@@ -64,7 +64,21 @@ def test_pixels_outside_the_sky_rectangle_are_sky(vra, ora, seed):
         assert np.isinf(want["depth"][out]).all() and (want["rgba8"][out] == 255).all()
         culled += int(out.sum()); total += out.size
         trivial += (x_lo, x_hi, y_lo, y_hi) == (0, f.tile_w - 1, 0, f.tile_h - 1)
+        # the spans the frame kernel culls with (rectangle cut by the hull's slanted edges), per tile row
+        for bh in (8, 2):
+            spans, hull = vra.gpu.sky_spans_for(hi, lo, f, bh)
+            assert spans.shape == ((f.tile_h + bh - 1) // bh, 2)
+            keep = np.zeros((f.tile_h, f.tile_w), bool)
+            for r, (a, b) in enumerate(spans):
+                if a <= b:
+                    assert x_lo <= a and b <= x_hi, (spans[r], x_lo, x_hi)
+                    keep[r * bh:(r + 1) * bh, a:b + 1] = True
+            bad = ~keep & ((want["hit_index"] != MISS) | (want["steps_lo"] != 0) | (want["steps_hi"] != 0))
+            assert not bad.any(), f"seed {seed} case {case} block_h {bh}: {int(bad.sum())} pixels outside their span are not sky (camera {pos}, hull {hull.tolist()})"
+            if bh == 8:
+                hull_culled += int((inside & ~keep).sum()); rect_area += int(inside.sum())
     assert culled > 0.15 * total, (culled, total)
+    assert hull_culled > 0, (hull_culled, rect_area)          # the slanted edges cut something off even these small rectangles (6 px of margins)
     assert 0 < trivial < 40                                  # cameras inside / close: no cull; far ones: cull
     scene.close()
 
@@ -88,3 +102,15 @@ def test_sky_rectangle_switches_itself_off(vra):
     assert vra.gpu.sky_rect_for(hi, None, n) != whole        # naive frames need no low grid
     with pytest.raises(vra.gpu.VollyError):
         vra.gpu.sky_rect_for(hi, None, f)
+
+
+def test_hull_edges_cut_the_rectangle_on_oblique_views(vra):
+    """At frame sizes where the margins are small, an oblique view's spans hold clearly fewer tiles than its rectangle."""
+    hi, lo = (1024,) * 3, (256,) * 3
+    f = vra.orbit_frames([300], 4096, hi, lo, 960, 540, radius=1.0)[0]
+    x_lo, x_hi, y_lo, y_hi = vra.gpu.sky_rect_for(hi, lo, f)
+    spans, hull = vra.gpu.sky_spans_for(hi, lo, f, 8)
+    rect_tiles = (x_hi // 8 - x_lo // 8 + 1) * (y_hi // 8 - y_lo // 8 + 1)
+    span_tiles = sum(b // 8 - a // 8 + 1 for a, b in spans if a <= b)
+    assert (hull[:, 2] != -1).sum() >= 3                    # slanted edges were found
+    assert span_tiles < 0.85 * rect_tiles, (span_tiles, rect_tiles)

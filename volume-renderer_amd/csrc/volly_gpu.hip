@@ -34,17 +34,18 @@ thread_local std::string g_err;
 // host code never uses the array's name as an address, only what hipGetSymbolAddress returned for
 // the device in question (noalloc_scratch below).
 namespace {
-constexpr size_t kNoAllocDescBytes = 4096;                 // vk::kInlineFrames descriptors of 176 B and cull rectangles of 16 B, padded
+constexpr size_t kNoAllocDescBytes = 4096;                 // vk::kInlineFrames descriptors of 176 B, padded
+constexpr size_t kNoAllocSpans = (size_t)128 << 10;        // 1 MiB of sky spans: one int2 per frame and tile row of a launch
 constexpr size_t kNoAllocCkptFloats = (size_t)8 << 20;     // 32 MiB of direction checkpoints: 6 * ceil(tile_w / 8) * tile_h floats per frame
 constexpr int kMaxDevices = 64;
 }
-static __device__ __align__(256) unsigned char scratch[kNoAllocDescBytes + kNoAllocCkptFloats * sizeof(float)];
+static __device__ __align__(256) unsigned char scratch[kNoAllocDescBytes + kNoAllocSpans * sizeof(int2) + kNoAllocCkptFloats * sizeof(float)];
 
 using namespace vimpl;
 
 namespace {
 constexpr int kFrameChunk = 64;     // most frames per launch (larger launches run closer to the kernel's steady rate: DESIGN.md section 5a)
-static_assert((sizeof(volly_frame_desc) + sizeof(int4)) * vk::kInlineFrames <= kNoAllocDescBytes, "descriptor part of the static scratch");
+static_assert(sizeof(volly_frame_desc) * vk::kInlineFrames <= kNoAllocDescBytes, "descriptor part of the static scratch");
 
 std::mutex g_scratch_mutex;
 void *g_scratch_ptr[kMaxDevices] = {};
@@ -163,6 +164,7 @@ void destroy(volly_gpu_scene *s)
     for (void *p : s->owned) (void)hipFree(p);
     if (s->d_frames) (void)hipFree(s->d_frames);
     if (s->d_ckpt) (void)hipFree(s->d_ckpt);
+    if (s->d_spans) (void)hipFree(s->d_spans);
     if (s->d_planes) (void)hipFree(s->d_planes);
     if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->s_render) (void)hipStreamDestroy(s->s_render);
@@ -178,7 +180,7 @@ int new_scene(int device, volly_gpu_scene **out)
     volly_gpu_scene *s = new (std::nothrow) volly_gpu_scene();
     if (!s) return fail(VOLLY_E_NOMEM, "host allocation failed");
     s->device = device;
-    if (const char *e = std::getenv("VOLLY_SKY_CULL")) s->sky_cull = std::atoi(e) != 0;      // 0: every tile sets its rays up (A/B runs)
+    if (const char *e = std::getenv("VOLLY_SKY_CULL")) s->sky_cull = std::atoi(e);           // 0: every tile sets its rays up, 1: rectangle only (A/B runs)
     {   // set-up is where the static scratch of the entry point that allocates nothing is looked up
         // (once per device, with that device current); a failure is reported by that entry point only
         DeviceGuard g(device);
@@ -291,7 +293,7 @@ constexpr double kSkyPixelMargin = 4.0, kSkyCellMargin = 1.0;
 
 struct SkyPass { double o[3], r0[3], xd[3], yd[3], size[3]; };
 
-static bool sky_project(const SkyPass &p, double &xmin, double &xmax, double &ymin, double &ymax)
+static bool sky_project(const SkyPass &p, double &xmin, double &xmax, double &ymin, double &ymax, double (*pts)[2] = nullptr)
 {
     // inverse of M = [xd | yd | r0] by cofactors
     const double *A = p.xd, *B = p.yd, *C = p.r0;
@@ -312,13 +314,67 @@ static bool sky_project(const SkyPass &p, double &xmin, double &xmax, double &ym
         if (!std::isfinite(a_) || !std::isfinite(b_) || !(c_ * nc > 1e-3 * len)) return false;   // a corner beside or behind the camera: no cull
         xmin = std::min(xmin, a_ / c_); xmax = std::max(xmax, a_ / c_);
         ymin = std::min(ymin, b_ / c_); ymax = std::max(ymax, b_ / c_);
+        if (pts) { pts[k][0] = a_ / c_; pts[k][1] = b_ / c_; }
     }
     return true;
 }
 
-static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc &f, bool enabled, int32_t out[4])
+// The slanted edges of the convex hull of the projected corners (pts: n points, absolute pixels) as
+// half-planes a*X + b*Y + c <= 0 with (a, b) the unit outward normal and the pixel margin in c: every
+// pixel whose ray can hit a box satisfies all of them (the box projects into the hull, as into the
+// rectangle).  Leaving an edge out only widens the region, so at most vk::kHullEdges are kept: those that
+// cut the most off the bounding rectangle (length x how far the edge is from axis-aligned -- the
+// rectangle already holds the axis-aligned ones).  Unused entries: (0, 0, -1).
+static void sky_hull_edges(const double (*pts)[2], int n, float out[vk::kHullEdges][3])
+{
+    for (int e = 0; e < vk::kHullEdges; ++e) { out[e][0] = 0.f; out[e][1] = 0.f; out[e][2] = -1.f; }
+    std::vector<std::pair<double, double>> p(n);
+    for (int i = 0; i < n; ++i) {
+        if (!std::isfinite(pts[i][0]) || !std::isfinite(pts[i][1]) || std::fabs(pts[i][0]) > 1e7 || std::fabs(pts[i][1]) > 1e7) return;
+        p[i] = {pts[i][0], pts[i][1]};
+    }
+    std::sort(p.begin(), p.end());
+    auto cross = [](const std::pair<double, double> &o, const std::pair<double, double> &a, const std::pair<double, double> &b) {
+        return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first);
+    };
+    std::vector<std::pair<double, double>> h(2 * (size_t)n);        // Andrew's monotone chain, counter-clockwise
+    int k = 0;
+    for (int i = 0; i < n; ++i) { while (k >= 2 && cross(h[k - 2], h[k - 1], p[i]) <= 0) --k; h[k++] = p[i]; }
+    for (int i = n - 2, t = k + 1; i >= 0; --i) { while (k >= t && cross(h[k - 2], h[k - 1], p[i]) <= 0) --k; h[k++] = p[i]; }
+    const int m = k - 1;                                              // hull vertices h[0..m-1]
+    if (m < 3) return;
+    struct Edge { double a, b, c, score; };
+    std::vector<Edge> edges;
+    for (int i = 0; i < m; ++i) {
+        const auto &u = h[i], &v = h[(i + 1) % m];
+        const double dx = v.first - u.first, dy = v.second - u.second, len = std::sqrt(dx * dx + dy * dy);
+        if (!(len > 1e-6)) continue;
+        const double a = dy / len, b = -dx / len;                      // outward normal of a counter-clockwise polygon
+        // every point must lie inside (the hull says so; rounding is covered by taking the support over all points)
+        double support = -1e300;
+        for (int j = 0; j < n; ++j) support = std::max(support, a * pts[j][0] + b * pts[j][1]);
+        edges.push_back({a, b, -(support + kSkyPixelMargin), len * std::min(std::fabs(a), std::fabs(b))});
+    }
+    std::sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) { return x.score > y.score; });
+    for (int e = 0; e < vk::kHullEdges && e < (int)edges.size(); ++e) {
+        if (!(edges[e].score > 1.0)) break;                           // axis-aligned: the rectangle has it
+        // to float, rounded so that the half-plane only grows: c towards -inf
+        const float a = (float)edges[e].a, b = (float)edges[e].b;
+        double support = -1e300;
+        for (int j = 0; j < n; ++j) support = std::max(support, (double)a * pts[j][0] + (double)b * pts[j][1]);
+        const double norm = std::sqrt((double)a * a + (double)b * b);
+        out[e][0] = a; out[e][1] = b;
+        out[e][2] = std::nextafterf((float)(-(support + kSkyPixelMargin * norm + 0.01)), -INFINITY);
+    }
+}
+
+static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc &f, bool enabled, int32_t out[4],
+                          float hull[vk::kHullEdges][3] = nullptr)
 {
     out[0] = 0; out[1] = f.tile_w - 1; out[2] = 0; out[3] = f.tile_h - 1;            // no cull
+    if (hull) for (int e = 0; e < vk::kHullEdges; ++e) { hull[e][0] = 0.f; hull[e][1] = 0.f; hull[e][2] = -1.f; }
+    double pts[16][2];
+    int n_pts = 0;
     if (!enabled || (f.flags & VOLLY_FRAME_RAYTRACE)) return;
     const bool naive = (f.flags & VOLLY_FRAME_NAIVE) != 0;
     SkyPass hi{}, lo{};
@@ -329,7 +385,8 @@ static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], co
     for (int a = 0; a < 3; ++a) { hi.size[a] = size_hi[a]; lo.size[a] = size_lo[a]; }
     double x0, x1, y0, y1;
     if (naive) {
-        if (!sky_project(hi, x0, x1, y0, y1)) return;
+        if (!sky_project(hi, x0, x1, y0, y1, pts)) return;
+        n_pts = 8;
     } else {
         // the target pass runs from scale * (a point of the low ray) along the target direction sum: both
         // sets of constants must give the same rays.  D_hi and scale * D_lo are linear in (x, y), so their
@@ -356,8 +413,9 @@ static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], co
         far = std::sqrt(far);
         if (!std::isfinite(far) || !(3.0 * far * worst <= 0.25 * kSkyCellMargin)) return;     // constants disagree: no cull
         double u0, u1, v0, v1;
-        if (!sky_project(lo, x0, x1, y0, y1) || !sky_project(hb, u0, u1, v0, v1)) return;
+        if (!sky_project(lo, x0, x1, y0, y1, pts) || !sky_project(hb, u0, u1, v0, v1, pts + 8)) return;
         x0 = std::min(x0, u0); x1 = std::max(x1, u1); y0 = std::min(y0, v0); y1 = std::max(y1, v1);
+        n_pts = 16;
     }
     // absolute pixels -> the sub-rectangle's, widened, clamped (an empty range culls everything)
     const double lo_x = std::floor(x0 - kSkyPixelMargin) - f.x0, hi_x = std::ceil(x1 + kSkyPixelMargin) - f.x0;
@@ -367,12 +425,13 @@ static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], co
     out[1] = (int32_t)std::max(std::min(hi_x, (double)f.tile_w - 1.0), -1.0);
     out[2] = (int32_t)std::min(std::max(lo_y, 0.0), (double)f.tile_h);
     out[3] = (int32_t)std::max(std::min(hi_y, (double)f.tile_h - 1.0), -1.0);
+    if (hull) sky_hull_edges(pts, n_pts, hull);
 }
 
-static void sky_rect(const volly_gpu_scene *s, const volly_frame_desc &f, bool enabled, int32_t out[4])
+static void sky_rect(const volly_gpu_scene *s, const volly_frame_desc &f, bool enabled, int32_t out[4], float hull[vk::kHullEdges][3] = nullptr)
 {
     const int32_t hi[3] = {s->target.sx, s->target.sy, s->target.sz}, lo[3] = {s->low.sx, s->low.sy, s->low.sz};
-    sky_rect_dims(hi, lo, f, enabled, out);
+    sky_rect_dims(hi, lo, f, enabled, out, hull);
 }
 
 size_t checkpoint_floats(const volly_frame_desc &f, int n)
@@ -381,20 +440,29 @@ size_t checkpoint_floats(const volly_frame_desc &f, int n)
 }
 
 // One launch of the pre-pass and the frame kernel for n <= kFrameChunk frames.  fixed_frames /
-// fixed_ckpt: scratch handed in by the entry point that allocates nothing (then n <=
-// vk::kInlineFrames, the checkpoints fit, and this function calls no allocating routine);
+// fixed_spans / fixed_ckpt: scratch handed in by the entry point that allocates nothing (then n <=
+// vk::kInlineFrames, checkpoints and spans fit, and this function calls no allocating routine);
 // null: the scene's own scratch, grown with hipMalloc as needed.
 int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size_t frame_offset, const volly_outputs *outs,
-                 hipStream_t stream, volly_frame_desc *fixed_frames = nullptr, float *fixed_ckpt = nullptr)
+                 hipStream_t stream, volly_frame_desc *fixed_frames = nullptr, int2 *fixed_spans = nullptr, float *fixed_ckpt = nullptr)
 {
     const int tw = frames[0].tile_w, th = frames[0].tile_h;
     const size_t need = checkpoint_floats(frames[0], n);
     if (need >= (1ull << 31)) return fail(VOLLY_E_ARG, "render: sub-rectangles of more than ~2^30 pixels per launch");
+    bool any_raytrace = false, all_naive = true;
+    for (int i = 0; i < n; ++i) {
+        any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
+        all_naive &= (frames[i].flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE)) == VOLLY_FRAME_NAIVE;
+    }
+    // launches of naive frames only are bound by the output path: 32 x 2 tiles (128-byte row segments); else 8 x 8
+    const int tile_w = all_naive ? vk::kTileNaive : vk::kTileBeam, block_w = tile_w * VK_WAVE_BLOCK, block_h = 64 / tile_w;
+    const size_t span_rows = (size_t)((th + block_h - 1) / block_h), need_spans = span_rows * (size_t)n;
     const bool no_alloc = fixed_frames != nullptr;
     volly_frame_desc *d_frames = fixed_frames;
+    int2 *d_spans = fixed_spans;
     float *d_ckpt = fixed_ckpt;
     if (!no_alloc) {
-        // The scene's scratch (descriptors, checkpoints) is reused by every call.  Calls on one stream
+        // The scene's scratch (descriptors, spans, checkpoints) is reused by every call.  Calls on one stream
         // are ordered by the stream; when the stream CHANGES, the new stream first waits for the event
         // the previous call recorded behind its last kernel, or its pre-pass would overwrite what that
         // kernel is still reading.  (The previous stream's handle is never touched again: the caller
@@ -407,32 +475,40 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         }
         s->scratch_stream = stream;
         s->scratch_in_use = true;
-        if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, (sizeof(volly_frame_desc) + sizeof(int4)) * kFrameChunk));   // descriptors, then cull rectangles
+        if (!s->d_frames) HIP_TRY(hipMalloc((void **)&s->d_frames, sizeof(volly_frame_desc) * kFrameChunk));
         if (need > s->ckpt_floats) {
             if (s->d_ckpt) { HIP_TRY(hipFree(s->d_ckpt)); s->d_ckpt = nullptr; s->ckpt_floats = 0; }
             HIP_TRY(hipMalloc((void **)&s->d_ckpt, need * sizeof(float)));
             s->ckpt_floats = need;
         }
+        if (need_spans > s->span_count) {
+            if (s->d_spans) { HIP_TRY(hipFree(s->d_spans)); s->d_spans = nullptr; s->span_count = 0; }
+            HIP_TRY(hipMalloc((void **)&s->d_spans, need_spans * sizeof(int2)));
+            s->span_count = need_spans;
+        }
         d_frames = s->d_frames;
+        d_spans = s->d_spans;
         d_ckpt = s->d_ckpt;
-    } else if (n > vk::kInlineFrames || need > kNoAllocCkptFloats)
+    } else if (n > vk::kInlineFrames || need > kNoAllocCkptFloats || need_spans > kNoAllocSpans)
         return fail(VOLLY_E_ARG, "render: batch does not fit the static scratch");
-    // the cull rectangles sit behind the descriptors (kFrameChunk of them in the scene's scratch,
-    // kInlineFrames in the static scratch of the entry point that allocates nothing)
-    int4 *d_cull = (int4 *)(d_frames + (no_alloc ? vk::kInlineFrames : kFrameChunk));
-    const bool cull_ok = s->sky_cull && !outs->pt_end;       // ptEnd of a miss is the reference's arithmetic: no shortcut
+    const int cull = outs->pt_end ? 0 : s->sky_cull;         // ptEnd of a miss is the reference's arithmetic: no shortcut
     // The descriptors travel as kernel arguments, kInlineFrames per pre-pass launch: no host-to-device copy (from
-    // pageable memory it would block the host and leave the queue empty between calls).  The pre-pass also leaves
-    // them, and the cull rectangles, in the scratch where the frame kernel reads them.
+    // pageable memory it would block the host and leave the queue empty between calls).  The pre-pass leaves
+    // them in the scratch where the frame kernel reads them, and turns each frame's sky rectangle and hull
+    // edges into one span of columns per tile row.
     for (int base = 0; base < n; base += vk::kInlineFrames) {
         const int nb = std::min(vk::kInlineFrames, n - base);
         vk::FrameBatch batch;
         std::memcpy(batch.f, frames + base, sizeof(volly_frame_desc) * (size_t)nb);
         std::memset(batch.f + nb, 0, sizeof(volly_frame_desc) * (size_t)(vk::kInlineFrames - nb));
         std::memset(batch.cull, 0, sizeof batch.cull);
-        for (int i = 0; i < nb; ++i) sky_rect(s, frames[base + i], cull_ok, batch.cull[i]);
+        std::memset(batch.hull, 0, sizeof batch.hull);
+        for (int i = 0; i < nb; ++i) {
+            sky_rect(s, frames[base + i], cull != 0, batch.cull[i], batch.hull[i]);
+            if (cull < 2) for (int e = 0; e < vk::kHullEdges; ++e) { batch.hull[i][e][0] = 0.f; batch.hull[i][e][1] = 0.f; batch.hull[i][e][2] = -1.f; }
+        }
         const dim3 pre_grid((unsigned)((th + 63) / 64), (unsigned)nb, 6);
-        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, nb, d_frames + base, d_cull + base, d_ckpt, base);
+        hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, nb, d_frames + base, d_spans, d_ckpt, base, block_h);
     }
     HIP_TRY(hipGetLastError());
 
@@ -452,13 +528,6 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         s->events.emplace_back(e0, e1);
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    bool any_raytrace = false, all_naive = true;
-    for (int i = 0; i < n; ++i) {
-        any_raytrace |= (frames[i].flags & VOLLY_FRAME_RAYTRACE) != 0;
-        all_naive &= (frames[i].flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE)) == VOLLY_FRAME_NAIVE;
-    }
-    // launches of naive frames only are bound by the output path: 32 x 2 tiles (128-byte row segments); else 8 x 8
-    const int tile_w = all_naive ? vk::kTileNaive : vk::kTileBeam, block_w = tile_w * VK_WAVE_BLOCK, block_h = 64 / tile_w;
     dim3 grid((unsigned)((tw + block_w - 1) / block_w), (unsigned)((th + block_h - 1) / block_h), (unsigned)n);
 #if VK_EXPERIMENTAL
     if (s->requeue && !any_raytrace && !no_alloc) {
@@ -501,19 +570,19 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
 #endif
     if (s->is_svo && all_naive)
         hipLaunchKernelGGL((vk::render_frames<true, false, vk::kTileNaive>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
-                           d_cull, d_ckpt, o);
+                           d_spans, d_ckpt, o);
     else if (s->is_svo)
         hipLaunchKernelGGL(vk::render_frames<true>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
-                           d_cull, d_ckpt, o);
+                           d_spans, d_ckpt, o);
     else if (any_raytrace)
         hipLaunchKernelGGL((vk::render_frames<false, true>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low,
-                           d_frames, d_cull, d_ckpt, o);
+                           d_frames, d_spans, d_ckpt, o);
     else if (all_naive)
         hipLaunchKernelGGL((vk::render_frames<false, false, vk::kTileNaive>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
-                           d_cull, d_ckpt, o);
+                           d_spans, d_ckpt, o);
     else
         hipLaunchKernelGGL(vk::render_frames<false>, grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
-                           d_cull, d_ckpt, o);
+                           d_spans, d_ckpt, o);
     HIP_TRY(hipGetLastError());
     if (e1) HIP_TRY(hipEventRecord(e1, stream));
     if (!no_alloc) {                                      // what a later call on another stream waits for
@@ -677,15 +746,19 @@ int volume_gpu_render_device_noalloc(volly_gpu_scene *scene, const volly_frame_d
                                      " bytes of direction checkpoints (6 * ceil(tile_w / 8) * tile_h floats), the static scratch holds " +
                                      std::to_string(kNoAllocCkptFloats * sizeof(float)) + ": render row bands, or use volume_gpu_render_device");
     volly_frame_desc *d_frames = (volly_frame_desc *)scene->noalloc_scratch;
-    float *d_ckpt = (float *)((unsigned char *)scene->noalloc_scratch + kNoAllocDescBytes);
-    const int chunk = (int)std::min<size_t>((size_t)vk::kInlineFrames, kNoAllocCkptFloats / per_frame);
+    int2 *d_spans = (int2 *)((unsigned char *)scene->noalloc_scratch + kNoAllocDescBytes);
+    float *d_ckpt = (float *)((unsigned char *)scene->noalloc_scratch + kNoAllocDescBytes + kNoAllocSpans * sizeof(int2));
+    const size_t span_rows = ((size_t)frames[0].tile_h + 1) / 2;          // at most: 32 x 2 tiles
+    if (span_rows > kNoAllocSpans)
+        return fail(VOLLY_E_ARG, "volume_gpu_render_device_noalloc: sub-rectangles of more than " + std::to_string(2 * kNoAllocSpans) + " rows");
+    const int chunk = (int)std::min<size_t>(std::min<size_t>((size_t)vk::kInlineFrames, kNoAllocCkptFloats / per_frame), kNoAllocSpans / span_rows);
     hipStream_t stream = (hipStream_t)hip_stream;
     // chunks follow each other on `stream`, so a chunk's pre-pass overwrites the scratch only after
     // the previous chunk's frame kernel has finished with it; nothing in it has to start at zero
     // (descriptors and checkpoints are written in full before they are read)
     for (int first = 0; first < n_frames; first += chunk) {
         const int n = std::min(chunk, n_frames - first);
-        if ((rc = render_chunk(scene, frames + first, n, (size_t)first, outs, stream, d_frames, d_ckpt))) return rc;
+        if ((rc = render_chunk(scene, frames + first, n, (size_t)first, outs, stream, d_frames, d_spans, d_ckpt))) return rc;
     }
     return VOLLY_OK;
 }
@@ -854,6 +927,24 @@ int volly_gpu_sky_rect_for(const int32_t size_hi[3], const int32_t size_lo[3], c
     const int32_t none[3] = {1, 1, 1};
     if (!size_lo && !(frame->flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE))) return fail(VOLLY_E_ARG, "a beam frame needs the low grid's size");
     sky_rect_dims(size_hi, size_lo ? size_lo : none, *frame, true, rect);
+    return VOLLY_OK;
+}
+
+int volly_gpu_sky_spans_for(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc *frame, int32_t block_h,
+                            int32_t *spans, float *hull_out)
+{
+    if (!size_hi || !frame || !spans || block_h < 1 || frame->tile_h < 1) return fail(VOLLY_E_ARG, "null argument or block_h < 1");
+    const int32_t none[3] = {1, 1, 1};
+    if (!size_lo && !(frame->flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE))) return fail(VOLLY_E_ARG, "a beam frame needs the low grid's size");
+    int32_t rect[4];
+    float hull[vk::kHullEdges][3];
+    sky_rect_dims(size_hi, size_lo ? size_lo : none, *frame, true, rect, hull);
+    const int rows = (frame->tile_h + block_h - 1) / block_h;
+    for (int r = 0; r < rows; ++r) {
+        const int2 sp = vk::sky_span(*frame, rect, &hull[0][0], r, block_h);
+        spans[2 * r] = sp.x; spans[2 * r + 1] = sp.y;
+    }
+    if (hull_out) std::memcpy(hull_out, hull, sizeof hull);
     return VOLLY_OK;
 }
 

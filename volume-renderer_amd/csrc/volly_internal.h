@@ -61,10 +61,12 @@ struct volly_gpu_scene {
     volly_frame_desc *d_frames = nullptr;
     float *d_ckpt = nullptr;
     size_t ckpt_floats = 0;
+    int2 *d_spans = nullptr;                // sky spans, one per frame and tile row of a launch
+    size_t span_count = 0;
     hipStream_t scratch_stream = nullptr;   // the stream the last call queued its use of the scratch on
     hipEvent_t scratch_event = nullptr;     // orders a call on another stream behind it (render_chunk)
     bool scratch_in_use = false;
-    bool sky_cull = true;           // tiles whose rays provably miss both grids write their miss values without ray set-up
+    int sky_cull = 2;               // tiles whose rays provably miss both grids write their miss values without ray set-up: 0 off, 1 bounding rectangle, 2 rectangle + hull edges
     void *d_planes = nullptr;       // staging of the synchronous entry point
     size_t plane_bytes = 0;
     hipStream_t s_render = nullptr, s_copy = nullptr;   // pinned-output path: render and copy-back overlap

@@ -1063,16 +1063,46 @@ __device__ __forceinline__ void checkpoint_chain(const volly_frame_desc &fd, int
 // when the caller's array is pageable).  The kernel also leaves the descriptors in frames_out,
 // where the frame kernel reads them.
 constexpr int kInlineFrames = 16;
+constexpr int kHullEdges = 5;
 // cull: per frame the pixel rectangle {x_lo, x_hi, y_lo, y_hi} (inclusive, relative to the sub-rectangle)
-// outside of which every ray provably misses both grids (host: sky_rect in volly_gpu.hip)
-struct FrameBatch { volly_frame_desc f[kInlineFrames]; int32_t cull[kInlineFrames][4]; };
-static_assert(sizeof(FrameBatch) <= 3072, "kernel arguments are limited to 4 KB");
+// outside of which every ray provably misses both grids (host: sky_rect in volly_gpu.hip).
+// hull: per frame up to kHullEdges half-planes a*X + b*Y + c <= 0 (absolute pixel coordinates, (a, b) a unit
+// vector, margin included) that hold the same pixels: the slanted edges of the projected boxes' convex hull
+// (host: sky_hull); an unused entry is (0, 0, -1).
+struct FrameBatch { volly_frame_desc f[kInlineFrames]; int32_t cull[kInlineFrames][4]; float hull[kInlineFrames][kHullEdges][3]; };
+static_assert(sizeof(FrameBatch) <= 4040, "kernel arguments are limited to 4 KB");
+
+// Sky spans: for the tile row `row` (rows row*block_h .. +block_h-1 of the sub-rectangle) the range of columns
+// [lo, hi] (relative to the sub-rectangle, inclusive) outside of which every ray of those rows misses both
+// grids; lo > hi: the whole tile row is sky.  The frame kernel's sky test is then two compares on one
+// 8-byte scalar load.  Double precision and two pixels of slack on top of the margin the half-planes carry.
+// (Host and device: volly_gpu_sky_spans_for runs the same function, for the CPU tests.)
+__host__ __device__ __forceinline__ int2 sky_span(const volly_frame_desc &fd, const int32_t *rect, const float *hull, int row, int block_h)
+{
+    const int y0 = row * block_h, y1 = (y0 + block_h - 1 < fd.tile_h - 1) ? y0 + block_h - 1 : fd.tile_h - 1;
+    int lo = rect[0], hi = rect[1];
+    if (y1 < rect[2] || y0 > rect[3]) return make_int2(1, 0);
+    const double Y0 = (double)(fd.y0 + y0), Y1 = (double)(fd.y0 + y1), X0 = (double)fd.x0, X1 = (double)(fd.x0 + fd.tile_w - 1);
+    for (int e = 0; e < kHullEdges; ++e) {
+        const double a = hull[3 * e], b = hull[3 * e + 1], c = hull[3 * e + 2];
+        const double rhs = -c - fmin(b * Y0, b * Y1);     // a*X <= rhs for a pixel of these rows that may hit
+        if (a > 1e-3) {
+            const double x = floor(rhs / a + 2.0) - X0;
+            if (x < (double)hi) hi = (int)fmax(x, -1.0);
+        } else if (a < -1e-3) {
+            const double x = ceil(rhs / a - 2.0) - X0;
+            if (x > (double)lo) lo = (int)fmin(x, (double)fd.tile_w);
+        } else if (fmin(a * X0, a * X1) > rhs + 0.5)
+            return make_int2(1, 0);
+    }
+    return make_int2(lo, hi);
+}
 
 // base: index of the batch's first frame in the launch (a launch of more than kInlineFrames frames takes one
-// pre-pass per kInlineFrames of them; frames_out and cull_out point at the batch's first entry).
+// pre-pass per kInlineFrames of them; frames_out points at the batch's first entry, spans_out at the launch's first).
 __global__ void __launch_bounds__(64)
-direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *__restrict__ frames_out, int4 *__restrict__ cull_out,
-                             float *__restrict__ ckpt, int base)
+direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *__restrict__ frames_out, int2 *__restrict__ spans_out,
+                             float *__restrict__ ckpt, int base, int block_h)
 {
     const int f = blockIdx.y;
     if (f >= n_frames) return;
@@ -1085,10 +1115,17 @@ direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *_
         const uint32_t *src = (const uint32_t *)(args + f);
         uint32_t *dst = (uint32_t *)(frames_out + f);
         for (unsigned w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
-        const int32_t *c = (const int32_t *)(args + kInlineFrames) + 4 * f;
-        if (threadIdx.x == 0) cull_out[f] = make_int4(c[0], c[1], c[2], c[3]);
     }
-    checkpoint_chain(args[f], base + f, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, ckpt);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.z == 0) {                                // one thread per tile row
+        const int span_rows = (args[f].tile_h + block_h - 1) / block_h;
+        if (t < span_rows) {
+            const int32_t *rect = (const int32_t *)(args + kInlineFrames) + 4 * f;
+            const float *hull = (const float *)((const int32_t *)(args + kInlineFrames) + 4 * kInlineFrames) + 3 * kHullEdges * f;
+            spans_out[(size_t)(base + f) * (size_t)span_rows + (size_t)t] = sky_span(args[f], rect, hull, t, block_h);
+        }
+    }
+    checkpoint_chain(args[f], base + f, blockIdx.z, t, ckpt);
 }
 
 // what one ray leaves behind (RaycastReport + the pixel, main.cpp:81-86,269-271)
@@ -1216,7 +1253,7 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
 template <bool SVO, bool RAYTRACE = false, int TW = kTileBeam>
 __global__ void __launch_bounds__(kFrameThreads) VK_FRAME_WAVES_ATTR
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
-              const int4 *__restrict__ cull, const float *__restrict__ ckpt, OutDev out)
+              const int2 *__restrict__ spans, const float *__restrict__ ckpt, OutDev out)
 {
     const int f = blockIdx.z;
     // uniform, read with scalar loads where it is used: a by-value copy keeps ~50 scalar registers
@@ -1229,12 +1266,12 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
     const int xrel = (int)blockIdx.x * kBlockW + wave * TW + (lane & (TW - 1));
     const int yrel = (int)blockIdx.y * kBlockH + (lane / TW);
     if ((xrel < fd.tile_w) & (yrel < fd.tile_h)) {       // eight 32-byte row segments per store instruction
-        // Sky tiles: outside the frame's cull rectangle every ray is known to end both passes at its
+        // Sky tiles: outside its tile row's span (sky_span) every ray is known to end both passes at its
         // first bounds test (0 steps, no hit -- what PixelOut starts as), so the 288-instruction
         // set-up of direction, rays and entry points is skipped.  Wave-uniform: the tile's corner.
-        const int4 rect = cull[f];
-        const int tx = (int)blockIdx.x * kBlockW + (VK_WAVE_BLOCK > 1 ? __builtin_amdgcn_readfirstlane(wave) * TW : 0), ty = (int)blockIdx.y * kBlockH;
-        const bool sky = (tx + TW - 1 < rect.x) | (tx > rect.y) | (ty + kBlockH - 1 < rect.z) | (ty > rect.w);
+        const int2 span = spans[(uint32_t)f * gridDim.y + blockIdx.y];
+        const int tx = (int)blockIdx.x * kBlockW + (VK_WAVE_BLOCK > 1 ? __builtin_amdgcn_readfirstlane(wave) * TW : 0);
+        const bool sky = (tx + TW - 1 < span.x) | (tx > span.y);
         PixelOut o;
         if (!sky) {
             const Ckpt k = load_checkpoint(ckpt, fd, f, xrel, yrel);

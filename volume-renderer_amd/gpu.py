@@ -47,6 +47,8 @@ _sig = {
     "volly_gpu_scene_info": (C.c_int64, [_vp, C.c_int]),
     "volly_gpu_sky_rect": (C.c_int, [_vp, C.POINTER(FrameDesc), C.POINTER(C.c_int32)]),
     "volly_gpu_sky_rect_for": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(FrameDesc), C.POINTER(C.c_int32)]),
+    "volly_gpu_sky_spans_for": (C.c_int, [C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(FrameDesc), C.c_int32, C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_float)]),
     "volly_gpu_free": (None, [_vp]),
     "volly_gpu_last_error": (C.c_char_p, []),
     "volly_gpu_abi_version": (C.c_int, []),
@@ -81,6 +83,20 @@ def _frames_array(frames):
     for i, f in enumerate(frames):
         arr[i] = f
     return arr, len(frames)
+
+
+def sky_spans_for(size_hi, size_lo, frame, block_h=8):
+    """volly_gpu_sky_spans_for: per tile row of `frame` the (first, last) column that may hold a ray entering a grid
+    (numpy int32 [rows, 2]; first > last: none), and the hull edges used (numpy float32 [5, 3]).  Host arithmetic, no GPU."""
+    import numpy as np
+    hi = (C.c_int32 * 3)(*[int(v) for v in size_hi])
+    lo = (C.c_int32 * 3)(*[int(v) for v in size_lo]) if size_lo is not None else None
+    rows = (frame.tile_h + block_h - 1) // block_h
+    spans = np.zeros((rows, 2), np.int32)
+    hull = np.zeros((5, 3), np.float32)
+    _check(lib.volly_gpu_sky_spans_for(hi, lo, C.byref(frame), block_h, spans.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       hull.ctypes.data_as(C.POINTER(C.c_float))), "volly_gpu_sky_spans_for")
+    return spans, hull
 
 
 def sky_rect_for(size_hi, size_lo, frame):
