@@ -491,7 +491,10 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         d_ckpt = s->d_ckpt;
     } else if (n > vk::kInlineFrames || need > kNoAllocCkptFloats || need_spans > kNoAllocSpans)
         return fail(VOLLY_E_ARG, "render: batch does not fit the static scratch");
-    const int cull = outs->pt_end ? 0 : s->sky_cull;         // ptEnd of a miss is the reference's arithmetic: no shortcut
+    int cull = outs->pt_end ? 0 : s->sky_cull;               // ptEnd of a miss is the reference's arithmetic: no shortcut
+#if VK_EXPERIMENTAL
+    if ((s->requeue || s->refill) && !any_raytrace && !no_alloc) cull = 0;   // those kernels have no sky test: every checkpoint is read
+#endif
     // The descriptors travel as kernel arguments, kInlineFrames per pre-pass launch: no host-to-device copy (from
     // pageable memory it would block the host and leave the queue empty between calls).  The pre-pass leaves
     // them in the scratch where the frame kernel reads them, and turns each frame's sky rectangle and hull

@@ -1031,10 +1031,12 @@ __device__ V4 raytrace(const DenseDev &g, float sx, float sy, float sz, V4 dir, 
 // A thread walks its chain -- y adds down to its row, then along the row -- and stores the
 // running sum every kCkpt pixels.  ckpt layout: [frame][column group][component][row], so
 // the 64 rows of a workgroup store 256 contiguous bytes.
-__device__ __forceinline__ void checkpoint_chain(const volly_frame_desc &fd, int f, int comp, int yrel, float *__restrict__ ckpt)
+// g_lo .. g_hi: the 8-pixel groups of this row whose checkpoints a tile that is not sky will read (sky_span);
+// the others are neither computed past nor stored.
+__device__ __forceinline__ void checkpoint_chain(const volly_frame_desc &fd, int f, int comp, int yrel, float *__restrict__ ckpt, int g_lo, int g_hi)
 {
     const int tile_w = fd.tile_w, tile_h = fd.tile_h, x0 = fd.x0;
-    if (yrel >= tile_h) return;
+    if (yrel >= tile_h || g_lo > g_hi) return;
     const int y = fd.y0 + yrel;
     const int lo = comp >= 3, k = comp - 3 * lo;
     float v = lo ? fd.row0_lo[k] : fd.row0_hi[k];
@@ -1050,9 +1052,10 @@ __device__ __forceinline__ void checkpoint_chain(const volly_frame_desc &fd, int
     const int groups = (tile_w + kCkpt - 1) / kCkpt;
     float *o = ckpt + ((size_t)f * (size_t)groups * 6 + (size_t)comp) * (size_t)tile_h + (size_t)yrel;
     const size_t stride = (size_t)tile_h * 6;
+    const int last = g_hi < groups - 1 ? g_hi : groups - 1;
     #pragma unroll 4
-    for (int g = 0; g < groups; ++g) {
-        o[(size_t)g * stride] = v;
+    for (int g = 0; g <= last; ++g) {
+        if (g >= g_lo) o[(size_t)g * stride] = v;
         #pragma unroll
         for (int i = 0; i < kCkpt; ++i) v = v + dx;
     }
@@ -1074,14 +1077,14 @@ static_assert(sizeof(FrameBatch) <= 4040, "kernel arguments are limited to 4 KB"
 
 // Sky spans: for the tile row `row` (rows row*block_h .. +block_h-1 of the sub-rectangle) the range of columns
 // [lo, hi] (relative to the sub-rectangle, inclusive) outside of which every ray of those rows misses both
-// grids; lo > hi: the whole tile row is sky.  The frame kernel's sky test is then two compares on one
+// grids; (INT_MAX, -1): the whole tile row is sky (the frame kernel's two compares then cull every tile).  The frame kernel's sky test is then two compares on one
 // 8-byte scalar load.  Double precision and two pixels of slack on top of the margin the half-planes carry.
 // (Host and device: volly_gpu_sky_spans_for runs the same function, for the CPU tests.)
 __host__ __device__ __forceinline__ int2 sky_span(const volly_frame_desc &fd, const int32_t *rect, const float *hull, int row, int block_h)
 {
     const int y0 = row * block_h, y1 = (y0 + block_h - 1 < fd.tile_h - 1) ? y0 + block_h - 1 : fd.tile_h - 1;
     int lo = rect[0], hi = rect[1];
-    if (y1 < rect[2] || y0 > rect[3]) return make_int2(1, 0);
+    if (y1 < rect[2] || y0 > rect[3]) return make_int2(0x7fffffff, -1);
     const double Y0 = (double)(fd.y0 + y0), Y1 = (double)(fd.y0 + y1), X0 = (double)fd.x0, X1 = (double)(fd.x0 + fd.tile_w - 1);
     for (int e = 0; e < kHullEdges; ++e) {
         const double a = hull[3 * e], b = hull[3 * e + 1], c = hull[3 * e + 2];
@@ -1093,9 +1096,9 @@ __host__ __device__ __forceinline__ int2 sky_span(const volly_frame_desc &fd, co
             const double x = ceil(rhs / a - 2.0) - X0;
             if (x > (double)lo) lo = (int)fmin(x, (double)fd.tile_w);
         } else if (fmin(a * X0, a * X1) > rhs + 0.5)
-            return make_int2(1, 0);
+            return make_int2(0x7fffffff, -1);
     }
-    return make_int2(lo, hi);
+    return lo > hi ? make_int2(0x7fffffff, -1) : make_int2(lo, hi);
 }
 
 // base: index of the batch's first frame in the launch (a launch of more than kInlineFrames frames takes one
@@ -1117,15 +1120,19 @@ direction_checkpoints_inline(FrameBatch batch, int n_frames, volly_frame_desc *_
         for (unsigned w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
     }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t *rect = (const int32_t *)(args + kInlineFrames) + 4 * f;
+    const float *hull = (const float *)((const int32_t *)(args + kInlineFrames) + 4 * kInlineFrames) + 3 * kHullEdges * f;
     if (blockIdx.z == 0) {                                // one thread per tile row
         const int span_rows = (args[f].tile_h + block_h - 1) / block_h;
-        if (t < span_rows) {
-            const int32_t *rect = (const int32_t *)(args + kInlineFrames) + 4 * f;
-            const float *hull = (const float *)((const int32_t *)(args + kInlineFrames) + 4 * kInlineFrames) + 3 * kHullEdges * f;
-            spans_out[(size_t)(base + f) * (size_t)span_rows + (size_t)t] = sky_span(args[f], rect, hull, t, block_h);
-        }
+        if (t < span_rows) spans_out[(size_t)(base + f) * (size_t)span_rows + (size_t)t] = sky_span(args[f], rect, hull, t, block_h);
     }
-    checkpoint_chain(args[f], base + f, blockIdx.z, t, ckpt);
+    if (t >= args[f].tile_h) return;
+    // the groups of row t that tiles inside its tile row's span cover (a tile is 64 / block_h pixels wide)
+    const int2 sp = sky_span(args[f], rect, hull, t / block_h, block_h);
+    const int tile_groups = 64 / block_h / kCkpt, tw_px = 64 / block_h;
+    const int g_lo = sp.x > sp.y ? 1 : (sp.x < 0 ? 0 : sp.x / tw_px) * tile_groups;
+    const int g_hi = sp.x > sp.y ? 0 : (sp.y < 0 ? 0 : sp.y / tw_px) * tile_groups + tile_groups - 1;
+    checkpoint_chain(args[f], base + f, blockIdx.z, t, ckpt, g_lo, g_hi);
 }
 
 // what one ray leaves behind (RaycastReport + the pixel, main.cpp:81-86,269-271)
