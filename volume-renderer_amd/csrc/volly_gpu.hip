@@ -289,6 +289,9 @@ int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, in
 // direction sum: the two sets of frame constants must describe the same rays (checked here at the
 // sub-rectangle's corners; a caller's inconsistent constants simply switch the cull off).
 // Returns the rectangle relative to the sub-rectangle, inclusive; the whole sub-rectangle = no cull.
+// The same holds for ANY half-plane that contains all projected corners: sky_hull_edges adds up to
+// vk::kHullEdges slanted ones, and the pre-pass kernel turns rectangle and edges into one span of columns
+// per tile row (vk::sky_span), which is what the frame kernel tests.
 constexpr double kSkyPixelMargin = 4.0, kSkyCellMargin = 1.0;
 
 struct SkyPass { double o[3], r0[3], xd[3], yd[3], size[3]; };

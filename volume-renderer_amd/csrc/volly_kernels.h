@@ -5,7 +5,8 @@
 //   * one ray per lane, one 64-lane wavefront per 8x8 pixel tile (32x2 for launches of naive
 //     frames only, which are bound by the output path), one wavefront per workgroup: a wave
 //     retires as soon as its 64 rays are done; tiles whose rays provably miss both grids
-//     write their miss values without setting a ray up (sky_rect, volly_gpu.hip);
+//     write their miss values without setting a ray up (per tile row a span of columns, sky_span
+//     below, from the projected boxes' rectangle and hull edges: sky_rect / sky_hull_edges, volly_gpu.hip);
 //   * the dense grids are traversed through a derived 1-bit occupancy structure
 //     (4x4x4-voxel bricks, one 64-bit word each) kept beside the reference's 8-byte
 //     voxels; the 8-byte Voxel (voxel.h:13-16) is fetched once, at the hit.  A
@@ -1071,13 +1072,14 @@ constexpr int kHullEdges = 5;
 // outside of which every ray provably misses both grids (host: sky_rect in volly_gpu.hip).
 // hull: per frame up to kHullEdges half-planes a*X + b*Y + c <= 0 (absolute pixel coordinates, (a, b) a unit
 // vector, margin included) that hold the same pixels: the slanted edges of the projected boxes' convex hull
-// (host: sky_hull); an unused entry is (0, 0, -1).
+// (host: sky_hull_edges in volly_gpu.hip); an unused entry is (0, 0, -1).
 struct FrameBatch { volly_frame_desc f[kInlineFrames]; int32_t cull[kInlineFrames][4]; float hull[kInlineFrames][kHullEdges][3]; };
 static_assert(sizeof(FrameBatch) <= 4040, "kernel arguments are limited to 4 KB");
 
 // Sky spans: for the tile row `row` (rows row*block_h .. +block_h-1 of the sub-rectangle) the range of columns
 // [lo, hi] (relative to the sub-rectangle, inclusive) outside of which every ray of those rows misses both
-// grids; (INT_MAX, -1): the whole tile row is sky (the frame kernel's two compares then cull every tile).  The frame kernel's sky test is then two compares on one
+// grids; (INT_MAX, -1): the whole tile row is sky (the frame kernel's two compares then cull every
+// tile of it).  The frame kernel's sky test is two compares on one
 // 8-byte scalar load.  Double precision and two pixels of slack on top of the margin the half-planes carry.
 // (Host and device: volly_gpu_sky_spans_for runs the same function, for the CPU tests.)
 __host__ __device__ __forceinline__ int2 sky_span(const volly_frame_desc &fd, const int32_t *rect, const float *hull, int row, int block_h)
