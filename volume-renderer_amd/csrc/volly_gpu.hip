@@ -141,7 +141,9 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
     if ((rc = dev_alloc(s, (void **)&occ2x, nr * 16))) return rc;
     int max_level = 7;                                    // empty cubes of up to 128^3 voxels; VOLLY_EMPTY_CUBES=4 switches them off (A/B runs)
     if (const char *e = std::getenv("VOLLY_EMPTY_CUBES")) max_level = std::min(std::max(std::atoi(e), 4), 7);
-    hipLaunchKernelGGL(vk::build_region_cubes, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, 0, occ2, d.nrx, d.nry, d.nrz, max_level, occ2x);
+    int boxes = 1;                                        // boxes may grow further along the axes that stay empty; VOLLY_EMPTY_BOXES=0: cubes only
+    if (const char *e = std::getenv("VOLLY_EMPTY_BOXES")) boxes = std::atoi(e) != 0;
+    hipLaunchKernelGGL(vk::build_region_cubes, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, 0, occ2, d.nrx, d.nry, d.nrz, max_level, boxes, occ2x);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     d.occ2x = occ2x;

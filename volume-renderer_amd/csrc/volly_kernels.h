@@ -1335,33 +1335,60 @@ __global__ void __launch_bounds__(256) build_occupancy2(const uint64_t *occ, int
 }
 
 // Region entries of the whole-traversal loop: the occ2 word plus, for an empty region, the key mask of
-// the largest aligned cube of 2^L voxels (L = 4..7) around it that is empty and lies inside the grid:
-// a lane that enters such a region stays quiet until its cell leaves the whole cube, not just the
-// 16^3 region (the headline workload then has a region change in 15 % of its wave-steps instead of
-// 25 %, tools/wave_step_census.py).  Mask = the bits of the packed cell x | y<<10 | z<<20 above L.
-__global__ void __launch_bounds__(256) build_region_cubes(const uint64_t *occ2, int nrx, int nry, int nrz, int max_level, uint4 *occ2x)
+// a large aligned box of 2^Lx x 2^Ly x 2^Lz voxels (L = 4..max_level per axis) around it that is empty
+// and lies inside the grid: a lane that enters such a region stays quiet until its cell leaves the whole
+// box, not just the 16^3 region.  With cubes (Lx = Ly = Lz) the headline workload has a region change in
+// 15 % of its wave-steps instead of 25 % (tools/wave_step_census.py); the box grows one axis at a time,
+// x, y, z in turn, as long as the doubled box is still empty (boxes = 0: all three together, cubes only),
+// so it holds the largest empty cube and extends beyond it along the axes that stay free (the slabs of
+// empty space above, below and beside a model).  Mask = the bits of the packed cell x | y<<10 | z<<20
+// above each axis' L: the loop's test `(cell & mask) == key` does not care that the levels differ.
+__global__ void __launch_bounds__(256) build_region_cubes(const uint64_t *occ2, int nrx, int nry, int nrz, int max_level, int boxes, uint4 *occ2x)
 {
     const size_t rg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nr = (size_t)nrx * nry * nrz;
     if (rg >= nr) return;
-    const int rx = (int)(rg % (size_t)nrx), ry = (int)((rg / (size_t)nrx) % (size_t)nry), rz = (int)(rg / ((size_t)nrx * nry));
+    const int r[3] = {(int)(rg % (size_t)nrx), (int)((rg / (size_t)nrx) % (size_t)nry), (int)(rg / ((size_t)nrx * nry))};
+    const int n[3] = {nrx, nry, nrz};
     const uint64_t word = occ2[rg];
-    int level = 4;
+    int L[3] = {4, 4, 4};
     if (word == 0) {
-        for (int L = 5; L <= max_level; ++L) {
-            const int b = 1 << (L - 4);                   // cube side in regions
-            const int x0 = rx & ~(b - 1), y0 = ry & ~(b - 1), z0 = rz & ~(b - 1);
-            bool empty = x0 + b <= nrx && y0 + b <= nry && z0 + b <= nrz;
-            for (int z = z0; empty && z < z0 + b; ++z)
-                for (int y = y0; empty && y < y0 + b; ++y)
-                    for (int x = x0; x < x0 + b; ++x)
-                        if (occ2[(size_t)x + (size_t)nrx * ((size_t)y + (size_t)nry * (size_t)z)]) { empty = false; break; }
-            if (!empty) break;
-            level = L;
+        auto empty_box = [&](const int *lv) {
+            int lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) {
+                const int b = 1 << (lv[a] - 4);               // box side in regions
+                lo[a] = r[a] & ~(b - 1);
+                hi[a] = lo[a] + b;
+                if (hi[a] > n[a]) return false;
+            }
+            for (int z = lo[2]; z < hi[2]; ++z)
+                for (int y = lo[1]; y < hi[1]; ++y)
+                    for (int x = lo[0]; x < hi[0]; ++x)
+                        if (occ2[(size_t)x + (size_t)nrx * ((size_t)y + (size_t)nry * (size_t)z)]) return false;
+            return true;
+        };
+        if (!boxes) {
+            for (int lv = 5; lv <= max_level; ++lv) {
+                const int t[3] = {lv, lv, lv};
+                if (!empty_box(t)) break;
+                L[0] = L[1] = L[2] = lv;
+            }
+        } else {
+            // (the best of the six axis orders by volume measured the same: r02_ab_boxorder_c*.log)
+            bool grew = true;
+            while (grew) {
+                grew = false;
+                for (int a = 0; a < 3; ++a) {
+                    if (L[a] >= max_level) continue;
+                    int t[3] = {L[0], L[1], L[2]};
+                    ++t[a];
+                    if (empty_box(t)) { L[a] = t[a]; grew = true; }
+                }
+            }
         }
     }
-    const uint32_t field = (1023u >> level) << level;
-    const uint32_t mask = 0xC0000000u | (field << 20) | (field << 10) | field;
+    const uint32_t fx = (1023u >> L[0]) << L[0], fy = (1023u >> L[1]) << L[1], fz = (1023u >> L[2]) << L[2];
+    const uint32_t mask = 0xC0000000u | (fz << 20) | (fy << 10) | fx;
     occ2x[rg] = make_uint4((uint32_t)word, (uint32_t)(word >> 32), mask, 0u);
 }
 
