@@ -31,8 +31,29 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 N_SIMDS = 1024                 # 256 CUs x 4 SIMDs
+# The bound that can bind this path: unfused FP32 vector arithmetic.  MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 vector
+# peak = 1024 SIMDs x 64 lanes / 2 cycles x 2.4 GHz x 2 flops per FMA.  The parity contract forbids FMA
+# (reference Makefile:3: -mavx without -mfma, so every glm::fma is a multiply and an add), which leaves one
+# flop per lane-op: 78.65 T lane-ops/s.
+VALU_PEAK_TLANEOPS = 157.3 / 2
+# the reference's own float operations: per DDA / octree step (main.cpp:122-153: 3 adds for the sample point,
+# 3 floor, 3 add, 3 sub, 3 mul, min3, 3 mul, 3 add) and per ray outside the loops (direction sums, two
+# normalisations, two ray set-ups, two entry clips, shading, depth: SURVEY 8d's "~ 40 * steps + 60" flops)
+OPS_PER_STEP, OPS_PER_RAY = 22, 60
 ORBIT_VIEWS = 4096             # SURVEY 8d config 5 orbit
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r02.json")   # written by profiles/summarize.py from rocprofv3 --pmc passes
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_r03.json")   # written by profiles/summarize.py from rocprofv3 --pmc passes
+LIB_PATH = os.path.join(ROOT, "volume-renderer_amd", "lib", "libvolly_gpu.so")
+
+# camera regimes (--camera): where the views of a step are taken from
+#   orbit    the orbit of SURVEY 8d at the preset's radius, looking at the volume's centre (the headline: the
+#            model seen whole from outside; most of a 16:9 frame is sky)
+#   startup  the reference's start-up state: camPos = 0, a corner of the grid (main.h:96), camDir from the mouse
+#            at (0, 0) (main.cpp:393-397); every ray starts at the grid, nothing is sky, the cull is off
+#   inside   the same orbit at radius 0.25: the camera is inside the grid (= the model's bounding box: normalizePoly
+#            stretches every mesh to the unit cube, PLYfileReader.cpp:144-171)
+#   fill     the same orbit at radius 0.5: the camera sits at the grid's faces and the model fills the frame
+#            (hit fraction 0.5 - 1.0 along the orbit)
+CAMERA_RADIUS = {"inside": 0.25, "fill": 0.5}
 
 # workload parameters (scene "noise" = volume_gpu_generate_noise; several scenes = alternate per step)
 PRESETS = {
@@ -65,6 +86,9 @@ def parse():
                     help="one frame per step split into row bands over the ranks + gather to rank 0 (config 4)")
     ap.add_argument("--mode", choices=["beam", "naive"], default="beam",
                     help="beam = raycast_beamOpt (the reference's live path); naive = traversal from the camera")
+    ap.add_argument("--camera", choices=["orbit", "startup", "inside", "fill"], default="orbit",
+                    help="camera regime of the step's views (see CAMERA_RADIUS above)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the untimed end-to-end block (host-buffer entry point)")
     ap.add_argument("--no-device-prepare", action="store_true",
                     help="skip the (untimed) run of volume_gpu_voxelize on the same mesh and its comparison with the host scene")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -79,7 +103,18 @@ def parse():
     for k, v in PRESETS[args.config].items():
         if getattr(args, k, None) is None:
             setattr(args, k, v)
+    if args.camera in CAMERA_RADIUS:
+        args.radius = CAMERA_RADIUS[args.camera]
     return args
+
+
+def lib_sha16():
+    """First 16 hex digits of the SHA-256 of the library this run loads: ties counter files to a build."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.environ.get("VOLLY_GPU_LIB") or LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def launch_ranks(n):
@@ -101,16 +136,27 @@ def launch_ranks(n):
     return worst
 
 
-def pmc_entry(key, rays_per_launch):
+def pmc_entry(key, rays_per_launch, sha):
     """Counter figures of this workload's dominant kernel from a separate rocprofv3 --pmc run
-    (profiles/run_pmc.sh + profiles/summarize.py), or None when that run was not made / had another shape."""
+    (profiles/run_pmc.sh + profiles/summarize.py), or None when that run was not made, had another
+    shape, or was taken on another build of the library (the file records the library's hash)."""
     try:
         e = json.load(open(PMC_FILE)).get(key)
     except Exception:
         return None
-    if not e or e.get("rays_per_launch") != rays_per_launch:
+    if not e or e.get("rays_per_launch") != rays_per_launch or not sha or e.get("lib_sha16") != sha:
         return None
     return e
+
+
+def binding_resource(pmc):
+    """Name what the counters say binds the kernel: the busiest of the resources they cover, or none."""
+    shares = {"vector-ALU issue": pmc.get("valu_issue_frac") or 0.0, "HBM": pmc.get("hbm_real_frac") or 0.0,
+              "texture addresser (vector memory issue)": pmc.get("ta_busy_frac") or 0.0}
+    name, top = max(shares.items(), key=lambda kv: kv[1])
+    if top < 0.6:
+        return f"none above 0.6 (busiest: {name} {top:.2f}): dependent-load latency and lane divergence"
+    return name
 
 
 def main():
@@ -172,16 +218,23 @@ def main():
         if name == "noise":
             gpus.append(vra.GpuScene.noise(args.res, seed=1, threshold=1 << (32 - args.noise_log2_inv_p), device=local_rank))
             host_scenes.append(None)
+        elif world > 1:
+            # N ranks: every rank builds its replica on its own GPU (volume_gpu_voxelize: 13-80 ms, byte-identical to
+            # the host pipeline -- tests/test_gpu_voxelize.py) instead of N host voxelizations sharing the node's cores
+            mesh = vra.HostMesh(os.path.join(ROOT, "assets", name), 2)
+            gpus.append(vra.GpuScene.voxelize(mesh.desc, args.res, dense=want_dense, svo=not want_dense, device=local_rank))
+            mesh.close()
+            host_scenes.append(None)
         else:
-            threads = 0 if world == 1 else max(2, 16 // min(world, 8))
-            sc = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", name), args.res, dense=want_dense, svo=not want_dense, threads=threads)
+            sc = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", name), args.res, dense=want_dense, svo=not want_dense, threads=0)
             gpus.append(vra.GpuScene.upload_dense(sc.target, sc.low, device=local_rank) if want_dense
                         else vra.GpuScene.upload_svo(sc.svo, sc.low, device=local_rank))
             host_scenes.append(sc)
     if names == ["noise"]:
         data = f"synthetic {args.res}^3 noise volume generated on the device (p = 2^-{args.noise_log2_inv_p}), synthetic orbit cameras"
     else:
-        data = f"bundled asset(s) {args.scene} voxelized on the host, synthetic orbit cameras"
+        data = (f"bundled asset(s) {args.scene} voxelized on the " + ("device (volume_gpu_voxelize, one replica per rank)" if world > 1 else "host")
+                + f", synthetic cameras ({args.camera})")
     size_hi, size_lo = (args.res,) * 3, (args.res // 4,) * 3
     setup_s = time.time() - t0
     scene, gpu = host_scenes[0], gpus[0]
@@ -240,18 +293,27 @@ def main():
             ks = [step % ORBIT_VIEWS]
         else:          # ranks interleave through the orbit: view k goes to rank k mod world
             ks = [((step * B + i) * world + rank) % orbit_n for i in range(B)]
-        frames = vra.orbit_frames(ks, orbit_n, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
+        if args.camera == "startup":     # main.h:96 + main.cpp:393-397 with the mouse at (0, 0): the same frame B times
+            view = vra.look_at((0, 0, 0), vra.host.cam_dir_from_mouse(0, 0), (0, 0, -1))
+            frames = (vra.FrameDesc * len(ks))()
+            for i in range(len(ks)):
+                frames[i] = vra.frame_from_camera(view, (0.0, 0.0, 0.0), size_hi, size_lo, W, H, naive=naive)
+        else:
+            frames = vra.orbit_frames(ks, orbit_n, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
         if split:
             frames[0] = frames[0].band(y0, rows)
         return frames
 
     all_frames = [step_frames(s) for s in range(args.warmup + args.steps)]
     assembled = [None]
+    # send buffer, receive list and the assembled frame are allocated once, outside the timed loop
+    gatherer = vra.shard.BandGatherer(H, W, rank, world, torch.int32, coll_dev) if split else None
 
     def run(s):
         gpus[s % len(gpus)].render_device(all_frames[s], ptrs, stream=stream.cuda_stream)
         if split:      # frame assembly on rank 0: the one collective of the path (RCCL gather over xGMI)
-            assembled[0] = vra.shard.gather_bands(planes["rgba8"][0].to(coll_dev), H, W, rank, world, dist, dst=0)
+            band = planes["rgba8"][0]
+            assembled[0] = gatherer.gather(band if coll_dev == dev else band.cpu(), dist)
 
     for s in range(args.warmup):
         run(s)
@@ -281,6 +343,29 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- per-rank figures: kernel time of every rank, and for the split the gather alone ----
+    per_rank_ms, gather_ms = None, None
+    if world > 1:
+        mine = torch.tensor([kern_ms / max(launches, 1)], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(v.item()), 4) for v in every]
+    if split and world > 1:            # untimed: the collective by itself, bands already rendered
+        band = planes["rgba8"][0] if coll_dev == dev else planes["rgba8"][0].cpu()
+        for _ in range(2):
+            gatherer.gather(band, dist)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        tg = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            gatherer.gather(band, dist)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        tgm = torch.tensor([(time.perf_counter() - tg) / reps * 1e3], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tgm, op=dist.ReduceOp.MAX)
+        gather_ms = round(float(tgm.item()), 4)
 
     # ---- algorithmic bytes of the timed launches (untimed re-render, exact integer sums) -----
     # B_ray = 8*(steps_lo + steps_hi) + 8*[hit] + 4 (pixel) + 16 (aux planes)
@@ -340,39 +425,108 @@ def main():
                    "dda_loop": ", ".join(g.dda_loops() for g in gpus),
                    "scene_setup_s": round(setup_s, 2), "scene_device_mib": sum(g.info(7) for g in gpus)},
     }
+    out["config"]["camera"] = args.camera
+    out["lib_sha16"] = lib_sha16()
     if assembled_ok is not None:
         out["config"]["assembled_frame_equals_single_gpu_frame"] = assembled_ok
+    if per_rank_ms is not None:
+        mean_ms = sum(per_rank_ms) / len(per_rank_ms)
+        out["per_rank_kernel_ms"] = per_rank_ms
+        out["load_imbalance"] = round(max(per_rank_ms) / mean_ms - 1.0, 4) if mean_ms > 0 else None
+    if gather_ms is not None:
+        out["gather_ms"] = gather_ms
+        out["gather_bytes_per_peer"] = int(vra.shard.band_rows(H, 0, world)[1] * W * 4)
     if prepare is not None:
         out["config"]["scene_prepared_on_device"] = prepare
     if launches:
         avg_ms = kern_ms / launches
         alg_per_launch = alg_bytes / launches
-        achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9
+        alg_gbs = alg_per_launch / (avg_ms * 1e-3) / 1e9
         kernel = "vk::render_frames<%s>" % ("true" if args.target == "svo" else "false")
-        # `roofline` is the contractual figure: ALGORITHMIC bytes (the reference layout's 8 B per executed
-        # sample) over the kernel time measured here with HIP events.  The kernel does not move
-        # those bytes -- it walks 1-bit occupancy words that stay in cache -- so `measured` carries what
-        # binds it (vector-ALU issue) and the real HBM rate, from rocprofv3 --pmc passes of this same
-        # workload made in separate runs (counters cannot be read inside this process).
-        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": kernel,
+        # `roofline`: the bound that can bind this path is unfused FP32 vector arithmetic -- the kernel walks
+        # 1-bit occupancy words that stay in cache (real HBM traffic is ~6 % of the algorithmic bytes), while every
+        # step's floats must be the reference's own 22 operations.  work = 22 x (exact sum of both step planes of the
+        # timed launches) + 60 x rays lane-ops; achieved = work / HIP-event kernel time; peak = 78.65 T lane-ops/s
+        # (157.3 TFLOP/s FP32 vector peak / 2: no FMA under the parity contract); frac <= 1 by construction of a
+        # kernel that executes those operations.  SURVEY 8d's algorithmic-byte figure (8 B per executed sample of
+        # the reference layout) stays beside it as hbm_algorithmic_*: it is not a utilisation and passes 1.
+        ops_per_launch = (OPS_PER_STEP * (sum_lo + sum_hi) + OPS_PER_RAY * rays_per_launch * args.steps) / launches
+        achieved = ops_per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "valu", "achieved": round(achieved, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s (unfused FP32)",
+                "frac": round(achieved / VALU_PEAK_TLANEOPS, 5), "traffic": None, "kernel": kernel,
                 "kernel_avg_ms": round(avg_ms, 4), "launches": launches,
-                "algorithmic_bytes_per_launch": int(alg_per_launch)}
-        pmc = pmc_entry(f"config{args.config}:{args.mode}" + ("" if args.noise_log2_inv_p == 8 else f":p{args.noise_log2_inv_p}"),
-                        rays_per_launch) if not split or world == 1 else None
+                "lane_ops_per_launch": int(ops_per_launch), "ops_per_step": OPS_PER_STEP, "ops_per_ray": OPS_PER_RAY,
+                "hbm_algorithmic_bytes_per_launch": int(alg_per_launch), "hbm_algorithmic_gbs": round(alg_gbs, 2),
+                "hbm_algorithmic_frac_of_8tbs": round(alg_gbs / HBM_PEAK_GBS, 5)}
+        sha = lib_sha16()
+        key = f"config{args.config}:{args.mode}" + ("" if args.camera == "orbit" else f":{args.camera}") + \
+              ("" if args.noise_log2_inv_p == 8 else f":p{args.noise_log2_inv_p}")
+        pmc = pmc_entry(key, rays_per_launch, sha) if not split or world == 1 else None
         if pmc:
             roof["traffic"] = pmc["hbm_bytes_per_launch"]
-            roof["traffic_source"] = pmc["source"] + " (rocprofv3 --pmc, separate run of this workload; 2*FETCH_SIZE + WRITE_SIZE)"
+            roof["traffic_source"] = pmc["source"] + " (rocprofv3 --pmc, separate run of this workload on this build; 2*FETCH_SIZE + WRITE_SIZE)"
             real_gbs = pmc["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            roof["hbm_real_gbs"] = round(real_gbs, 1)
+            roof["hbm_real_frac"] = round(real_gbs / HBM_PEAK_GBS, 4)
+            pmc = dict(pmc, hbm_real_frac=real_gbs / HBM_PEAK_GBS)
             out["measured"] = {
-                "binding_resource": "vector-ALU issue",
+                "binding_resource": binding_resource(pmc),
                 "valu_issue_frac": pmc["valu_issue_frac"],
                 "valu_issue_frac_def": "SQ_INSTS_VALU / (1024 SIMDs * kernel cycles / 2): share of the one-wave64-instruction-per-2-cycles issue peak",
+                "valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
                 "hbm_real_gbs": round(real_gbs, 1), "hbm_real_frac": round(real_gbs / HBM_PEAK_GBS, 4),
                 "l2_read_hit_rate": pmc["l2_read_hit_rate"], "waves_per_simd": pmc["waves_per_simd"],
-                "active_lanes_avg": pmc["active_lanes_avg"], "pmc_kernel_avg_ms": pmc["kernel_avg_ms"],
-                "source": pmc["source"]}
+                "active_lanes_avg": pmc["active_lanes_avg"], "ta_busy_frac": pmc.get("ta_busy_frac"),
+                "pmc_kernel_avg_ms": pmc["kernel_avg_ms"],
+                "lib_sha16": pmc.get("lib_sha16"), "git_head": pmc.get("git_head"), "source": pmc["source"]}
         out["roofline"] = roof
+
+    # ---- end to end (untimed relative to `value`): the synchronous host-buffer entry point
+    # volume_gpu_render into pinned memory -- the reference's contract is pixels in the locked texture
+    # (main.h:38-42, main.cpp:269-271,290) -- for one step's frames, and the reference's own call shape:
+    # one 400x300 frame per call (main.h:112, main.cpp:314)
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        try:
+            import numpy as np
+            import statistics
+            e2e = {}
+            frames = all_frames[args.warmup]
+            g0 = gpus[args.warmup % len(gpus)]
+            for label, names_ in (("rgba8_only", ("rgba8",)), ("five_planes", plane_names)):
+                pinned = {p: vra.PinnedArray((B, rows, W), np.float32 if p == "depth" else np.uint32) for p in names_}
+                arrays = {p: a.array for p, a in pinned.items()}
+                ts = []
+                for _ in range(4):
+                    t1 = time.perf_counter()
+                    g0.render_into(frames, arrays)
+                    ts.append(time.perf_counter() - t1)
+                ms = statistics.median(ts[1:]) * 1e3
+                e2e[label] = {"ms_per_call": round(ms, 3), "mrays_per_s": round(B * rows * W / ms / 1e3, 1),
+                              "pcie_gbs": round(len(names_) * 4 * B * rows * W / ms / 1e6, 2)}
+                for a in pinned.values():
+                    a.close()
+            w1, h1 = 400, 300
+            if args.camera == "startup":
+                view = vra.look_at((0, 0, 0), vra.host.cam_dir_from_mouse(0, 0), (0, 0, -1))
+                one = [vra.frame_from_camera(view, (0.0, 0.0, 0.0), size_hi, size_lo, w1, h1, naive=naive)]
+            else:
+                one = vra.orbit_frames([args.warmup * B % orbit_n], orbit_n, size_hi, size_lo, w1, h1, radius=args.radius, naive=naive)
+            px = vra.PinnedArray((1, h1, w1), np.uint32)
+            ts = []
+            for _ in range(220):
+                t1 = time.perf_counter()
+                g0.render_into(one, {"rgba8": px.array})
+                ts.append(time.perf_counter() - t1)
+            ts = sorted(ts[20:])
+            e2e["reference_call_shape_400x300"] = {"latency_us_median": round(ts[len(ts) // 2] * 1e6, 1), "latency_us_p90": round(ts[int(len(ts) * 0.9)] * 1e6, 1),
+                                                   "mrays_per_s": round(w1 * h1 / ts[len(ts) // 2] / 1e6, 1), "calls": len(ts),
+                                                   "what": "one 400x300 frame per volume_gpu_render call, rgba8 into pinned host memory, call to return"}
+            px.close()
+            e2e["entry_point"] = "volume_gpu_render (synchronous, outputs in pinned host memory)"
+            e2e["frames_per_call"] = B
+            out["end_to_end"] = e2e
+        except Exception as e:      # reported, never fatal: this is not the measured path
+            out["end_to_end"] = {"error": str(e)[:200]}
 
     # ---- CPU baseline: the oracle, one thread (the reference is single threaded), bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline and scene is not None:

@@ -4,7 +4,9 @@ profiles/<tag>/:
   <key>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of that workload
   pmc_summary.csv          per-launch mean of every counter of the frame kernel, one block per workload,
                            followed by the derived figures
-  and profiles/pmc_<tag>.json, which bench.py attaches to its JSON line (roofline.traffic, `measured`).
+  and profiles/pmc_<tag>.json, which bench.py attaches to its JSON line (roofline.traffic, `measured`) --
+  each entry stamped with the hash of the library the counters were taken on (lib_sha16, from the bench line
+  of the trace run) and the git head at the time of condensing; bench.py ignores entries of another build.
 
 Derived figures (per launch of vk::render_frames<...>):
   cycles            = GRBM_GUI_ACTIVE / 8                       (the counter sums the 8 XCDs)
@@ -26,6 +28,13 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 summary, table = {}, []
+import subprocess
+try:
+    git_head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    if subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "volume-renderer_amd", "include"], capture_output=True, text=True).stdout.strip():
+        git_head += "+uncommitted"
+except Exception:
+    git_head = None
 for kdir in sorted(glob.glob(os.path.join(src, "*", ""))):
     key = os.path.basename(kdir.rstrip("/"))
     stats = glob.glob(os.path.join(kdir, "trace", "**", "*kernel_stats.csv"), recursive=True)
@@ -77,6 +86,11 @@ for kdir in sorted(glob.glob(os.path.join(src, "*", ""))):
     if kern_ms and "hbm_bytes_per_launch" in d:
         d["hbm_real_gbs_under_rocprof"] = round(d["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1)
     cfg = bench.get("config", {})
+    if g("SQ_INSTS_VALU"):
+        d["valu_insts_per_launch"] = int(g("SQ_INSTS_VALU"))
+    # the build the counters were taken on: bench.py drops `measured` when the library it loads has another hash
+    d["lib_sha16"] = bench.get("lib_sha16")
+    d["git_head"] = git_head
     d["rays_per_launch"] = cfg.get("rays_per_step")
     d["workload"] = cfg.get("workload")
     d["source"] = f"profiles/{tag}/pmc_summary.csv [{key}]"

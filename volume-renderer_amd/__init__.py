@@ -11,4 +11,5 @@ Python here is plumbing only (ctypes over the two shared libraries):
 """
 from . import host, gpu, shard   # noqa: F401
 from .host import HostScene, HostMesh, LodSet, frame_from_camera, orbit_camera, look_at, orbit_frames  # noqa: F401
-from .gpu import GpuScene, VollyError  # noqa: F401
+from .gpu import GpuScene, VollyError, PinnedArray  # noqa: F401
+from ._abi import FrameDesc  # noqa: F401

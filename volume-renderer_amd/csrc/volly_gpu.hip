@@ -277,14 +277,15 @@ int validate_frames(const volly_gpu_scene *s, const volly_frame_desc *frames, in
 // bounds test (main.cpp:126-135 on the first iteration: 0 steps, no hit, depth +inf, pixel 255,0,0,0),
 // so that the frame kernel can write those values without setting the ray up.
 //
-// The serial direction sum of pixel (x, y) is row0 + y*ydiff + x*xdiff up to rounding (at most
-// ~6000 additions of values below 4: under one pixel spacing in the worst case), so a box corner Q
+// The serial direction sum of pixel (x, y) is row0 + y*ydiff + x*xdiff up to rounding (width + height
+// additions of values in GRID units; how far that can drift, in pixels, is sky_drift_margin: 0.8 px at 4K,
+// 3 px at 8K, and it grows with the frame's area), so a box corner Q
 // is seen at the pixel (a/c, b/c) where Q - origin = a*xdiff + b*ydiff + c*row0, and it lies in front
 // of the camera iff c > 0.  With all eight corners of a box in front, every point of the box is a
 // convex combination of them with positive weights c_i, so its pixel lies in the corners' bounding
 // rectangle: a ray through a pixel outside that rectangle misses the box.  Boxes are the grids
 // widened by a margin (one cell beyond the reference's own (-1, size) test) and the rectangle by
-// kSkyPixelMargin pixels, which dwarf every rounding error of the reference's arithmetic for a point
+// kSkyPixelMargin pixels plus three times the drift bound, which dwarf every rounding error of the reference's arithmetic for a point
 // within 10^6 cells; farther points are outside any grid anyway.  Every point the reference computes
 // lies on (or within rounding of) its ray or is not finite, and both kinds fail the bounds test.
 // In beam mode the target pass starts on the low ray (scale * ptEnd) and runs along the TARGET
@@ -330,47 +331,71 @@ static bool sky_project(const SkyPass &p, double &xmin, double &xmax, double &ym
 // rectangle).  Leaving an edge out only widens the region, so at most vk::kHullEdges are kept: those that
 // cut the most off the bounding rectangle (length x how far the edge is from axis-aligned -- the
 // rectangle already holds the axis-aligned ones).  Unused entries: (0, 0, -1).
-static void sky_hull_edges(const double (*pts)[2], int n, float out[vk::kHullEdges][3])
+static void sky_hull_edges(const double (*pts)[2], int n, double margin, float out[vk::kHullEdges][3])
 {
+    // fixed arrays, no heap: the entry point that allocates nothing runs this for every frame
+    constexpr int kMaxPts = 16;
+    struct P { double x, y; };
     for (int e = 0; e < vk::kHullEdges; ++e) { out[e][0] = 0.f; out[e][1] = 0.f; out[e][2] = -1.f; }
-    std::vector<std::pair<double, double>> p(n);
+    if (n < 3 || n > kMaxPts) return;
+    P p[kMaxPts];
     for (int i = 0; i < n; ++i) {
         if (!std::isfinite(pts[i][0]) || !std::isfinite(pts[i][1]) || std::fabs(pts[i][0]) > 1e7 || std::fabs(pts[i][1]) > 1e7) return;
         p[i] = {pts[i][0], pts[i][1]};
     }
-    std::sort(p.begin(), p.end());
-    auto cross = [](const std::pair<double, double> &o, const std::pair<double, double> &a, const std::pair<double, double> &b) {
-        return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first);
-    };
-    std::vector<std::pair<double, double>> h(2 * (size_t)n);        // Andrew's monotone chain, counter-clockwise
+    std::sort(p, p + n, [](const P &a, const P &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });      // in place
+    auto cross = [](const P &o, const P &a, const P &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
+    P h[2 * kMaxPts];                                                 // Andrew's monotone chain, counter-clockwise
     int k = 0;
     for (int i = 0; i < n; ++i) { while (k >= 2 && cross(h[k - 2], h[k - 1], p[i]) <= 0) --k; h[k++] = p[i]; }
     for (int i = n - 2, t = k + 1; i >= 0; --i) { while (k >= t && cross(h[k - 2], h[k - 1], p[i]) <= 0) --k; h[k++] = p[i]; }
     const int m = k - 1;                                              // hull vertices h[0..m-1]
     if (m < 3) return;
-    struct Edge { double a, b, c, score; };
-    std::vector<Edge> edges;
+    struct Edge { double a, b, score; };
+    Edge edges[2 * kMaxPts];
+    int n_edges = 0;
     for (int i = 0; i < m; ++i) {
-        const auto &u = h[i], &v = h[(i + 1) % m];
-        const double dx = v.first - u.first, dy = v.second - u.second, len = std::sqrt(dx * dx + dy * dy);
+        const P &u = h[i], &v = h[(i + 1) % m];
+        const double dx = v.x - u.x, dy = v.y - u.y, len = std::sqrt(dx * dx + dy * dy);
         if (!(len > 1e-6)) continue;
         const double a = dy / len, b = -dx / len;                      // outward normal of a counter-clockwise polygon
-        // every point must lie inside (the hull says so; rounding is covered by taking the support over all points)
-        double support = -1e300;
-        for (int j = 0; j < n; ++j) support = std::max(support, a * pts[j][0] + b * pts[j][1]);
-        edges.push_back({a, b, -(support + kSkyPixelMargin), len * std::min(std::fabs(a), std::fabs(b))});
+        edges[n_edges++] = {a, b, len * std::min(std::fabs(a), std::fabs(b))};
     }
-    std::sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) { return x.score > y.score; });
-    for (int e = 0; e < vk::kHullEdges && e < (int)edges.size(); ++e) {
+    std::sort(edges, edges + n_edges, [](const Edge &x, const Edge &y) { return x.score > y.score; });
+    for (int e = 0; e < vk::kHullEdges && e < n_edges; ++e) {
         if (!(edges[e].score > 1.0)) break;                           // axis-aligned: the rectangle has it
-        // to float, rounded so that the half-plane only grows: c towards -inf
+        // to float, rounded so that the half-plane only grows: c towards -inf.  Every point must lie inside
+        // (the hull says so; rounding is covered by taking the support over all points)
         const float a = (float)edges[e].a, b = (float)edges[e].b;
         double support = -1e300;
         for (int j = 0; j < n; ++j) support = std::max(support, (double)a * pts[j][0] + (double)b * pts[j][1]);
         const double norm = std::sqrt((double)a * a + (double)b * b);
         out[e][0] = a; out[e][1] = b;
-        out[e][2] = std::nextafterf((float)(-(support + kSkyPixelMargin * norm + 0.01)), -INFINITY);
+        out[e][2] = std::nextafterf((float)(-(support + margin * norm + 0.01)), -INFINITY);
     }
+}
+
+// Pixels by which the reference's serial direction sums (main.cpp:282-286) can drift from
+// row0 + y*ydiff + x*xdiff, times three.  The sums are in grid units (iMV = scale(size) * inverse(view),
+// main.cpp:204-221): each of the up to width + height additions rounds a value of magnitude |v| by at
+// most 2^-24 |v| per component, and a constant increment rounds the same way inside a binade, so the
+// errors can add up rather than cancel.  One pixel spacing is |xdiff| (|ydiff|), so the drift is at most
+// (width + height) * 2^-24 * sqrt(3) * max|v| / min(|xdiff|, |ydiff|) pixels across the direction, and
+// about as much again through the perspective division at the frame's edge: 0.8 px at 4K, 3 px at
+// 7680x4320, 14 px at 16K.  The cull margin is kSkyPixelMargin + three times that bound.
+static double sky_drift_margin(const SkyPass &p, const volly_frame_desc &f)
+{
+    double vmax = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        const double x = (k & 1) ? f.width - 1 : 0, y = (k & 2) ? f.height - 1 : 0;
+        for (int a = 0; a < 3; ++a) vmax = std::max(vmax, std::fabs(p.r0[a] + y * p.yd[a] + x * p.xd[a]));
+    }
+    const double nx = std::sqrt(p.xd[0] * p.xd[0] + p.xd[1] * p.xd[1] + p.xd[2] * p.xd[2]);
+    const double ny = std::sqrt(p.yd[0] * p.yd[0] + p.yd[1] * p.yd[1] + p.yd[2] * p.yd[2]);
+    const double spacing = std::min(nx, ny);
+    if (!(spacing > 0.0) || !std::isfinite(vmax)) return INFINITY;
+    const double drift = ((double)f.width + (double)f.height) * std::ldexp(1.0, -24) * std::sqrt(3.0) * vmax / spacing;
+    return std::ceil(3.0 * drift);
 }
 
 static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], const volly_frame_desc &f, bool enabled, int32_t out[4],
@@ -389,6 +414,10 @@ static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], co
     }
     for (int a = 0; a < 3; ++a) { hi.size[a] = size_hi[a]; lo.size[a] = size_lo[a]; }
     double x0, x1, y0, y1;
+    // the pixel margin grows with the frame: the serial sums drift (sky_drift_margin); both passes' constants
+    // describe the same rays (checked below), so the larger of the two bounds serves both
+    const double margin = kSkyPixelMargin + std::max(sky_drift_margin(hi, f), naive ? 0.0 : sky_drift_margin(lo, f));
+    if (!std::isfinite(margin) || margin > 4096.0) return;
     if (naive) {
         if (!sky_project(hi, x0, x1, y0, y1, pts)) return;
         n_pts = 8;
@@ -423,14 +452,14 @@ static void sky_rect_dims(const int32_t size_hi[3], const int32_t size_lo[3], co
         n_pts = 16;
     }
     // absolute pixels -> the sub-rectangle's, widened, clamped (an empty range culls everything)
-    const double lo_x = std::floor(x0 - kSkyPixelMargin) - f.x0, hi_x = std::ceil(x1 + kSkyPixelMargin) - f.x0;
-    const double lo_y = std::floor(y0 - kSkyPixelMargin) - f.y0, hi_y = std::ceil(y1 + kSkyPixelMargin) - f.y0;
+    const double lo_x = std::floor(x0 - margin) - f.x0, hi_x = std::ceil(x1 + margin) - f.x0;
+    const double lo_y = std::floor(y0 - margin) - f.y0, hi_y = std::ceil(y1 + margin) - f.y0;
     if (!std::isfinite(lo_x) || !std::isfinite(hi_x) || !std::isfinite(lo_y) || !std::isfinite(hi_y)) return;
     out[0] = (int32_t)std::min(std::max(lo_x, 0.0), (double)f.tile_w);
     out[1] = (int32_t)std::max(std::min(hi_x, (double)f.tile_w - 1.0), -1.0);
     out[2] = (int32_t)std::min(std::max(lo_y, 0.0), (double)f.tile_h);
     out[3] = (int32_t)std::max(std::min(hi_y, (double)f.tile_h - 1.0), -1.0);
-    if (hull) sky_hull_edges(pts, n_pts, hull);
+    if (hull) sky_hull_edges(pts, n_pts, margin, hull);
 }
 
 static void sky_rect(const volly_gpu_scene *s, const volly_frame_desc &f, bool enabled, int32_t out[4], float hull[vk::kHullEdges][3] = nullptr)

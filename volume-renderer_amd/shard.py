@@ -29,23 +29,40 @@ def band_frame(frame, rank, world):
     return frame.band(y0, rows)
 
 
+class BandGatherer:
+    """Frame assembly of the single-frame split with every buffer allocated once: the padded send
+    buffer of this rank, and on `dst` the receive list and the assembled (height, width) frame.
+    Bands may differ by one row, so they travel padded to the tallest band and are trimmed on arrival.
+    gather() runs the one collective of the path (dist.gather: RCCL over xGMI under "nccl") and
+    returns the frame on dst, None elsewhere; the returned tensor is reused by the next call."""
+
+    def __init__(self, height, width, rank, world, dtype, device, dst=0):
+        import torch
+        self.height, self.width, self.rank, self.world, self.dst = height, width, rank, world, dst
+        self.rows = band_rows(height, rank, world)[1]
+        tallest = band_rows(height, 0, world)[1]
+        self.send = torch.zeros((tallest, width), dtype=dtype, device=device)
+        self.parts = self.frame = None
+        if rank == dst and world > 1:
+            self.parts = [torch.empty_like(self.send) for _ in range(world)]
+            self.frame = torch.empty((height, width), dtype=dtype, device=device)
+
+    def gather(self, band, dist):
+        if self.world == 1:
+            return band
+        assert tuple(band.shape) == (self.rows, self.width), (tuple(band.shape), self.rows, self.width)
+        self.send[:self.rows].copy_(band)
+        if self.rank != self.dst:
+            dist.gather(self.send, gather_list=None, dst=self.dst)
+            return None
+        dist.gather(self.send, gather_list=self.parts, dst=self.dst)
+        for r in range(self.world):
+            y0, rows = band_rows(self.height, r, self.world)
+            self.frame[y0:y0 + rows].copy_(self.parts[r][:rows])
+        return self.frame
+
+
 def gather_bands(band, height, width, rank, world, dist, dst=0):
-    """Assemble a (height, width) plane on rank `dst` from each rank's (rows, width)
-    torch tensor.  Bands may differ by one row, so they are padded to the tallest
-    band for the collective and trimmed afterwards.  Returns the frame on dst, else None."""
-    import torch
-    tallest = band_rows(height, 0, world)[1]
-    padded = band
-    if band.shape[0] < tallest:
-        pad = torch.zeros((tallest - band.shape[0], width), dtype=band.dtype, device=band.device)
-        padded = torch.cat([band, pad], dim=0)
-    padded = padded.contiguous()
-    if world == 1:
-        return band
-    if rank == dst:
-        parts = [torch.empty_like(padded) for _ in range(world)]
-        dist.gather(padded, gather_list=parts, dst=dst)
-        rows = [parts[r][:band_rows(height, r, world)[1]] for r in range(world)]
-        return torch.cat(rows, dim=0)
-    dist.gather(padded, gather_list=None, dst=dst)
-    return None
+    """One-off form of BandGatherer: assemble a (height, width) plane on rank `dst` from each
+    rank's (rows, width) torch tensor.  Returns the frame on dst, else None."""
+    return BandGatherer(height, width, rank, world, band.dtype, band.device, dst).gather(band.contiguous(), dist)
