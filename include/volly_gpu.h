@@ -89,7 +89,9 @@ typedef struct {
     float   scale_lo_to_hi[4];                      /* scaleLowptoHighp                main.cpp:239     */
     int32_t width, height;                          /* renderTargetSizeX/Y             main.h:112       */
     int32_t x0, y0, tile_w, tile_h;                 /* sub-rectangle rendered by this call (multi-GPU row bands) */
-    int32_t flags;                                  /* VOLLY_FRAME_BEAM / VOLLY_FRAME_NAIVE */
+    int32_t flags;                                  /* VOLLY_FRAME_BEAM (0: raycast_beamOpt, main.cpp:260), VOLLY_FRAME_NAIVE (traversal from the camera,
+                                                       the commented call at main.cpp:261) or VOLLY_FRAME_RAYTRACE (raytrace_naiive, main.cpp:170-194 with the
+                                                       commented call site main.cpp:274-278; dense targets only, pixel = the blended colour) */
     int32_t reserved;
 } volly_frame_desc;
 
@@ -247,7 +249,11 @@ int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leav
  *    nearly all hold voxels), 3 = the fully checked compiled loop -- taken by every grid with an axis
  *    that is not a multiple of 16 or is larger than 1024, measured ~16 % slower; wavefronts holding a
  *    ray with a zero / denormal / NaN direction component take loop 3 whatever the grid,
- * 15 the same for the LOW (beam) grid, 0 = no low grid. */
+ * 15 the same for the LOW (beam) grid, 0 = no low grid,
+ * 16 octree targets: 1 = traversed through the flattened tree (direct-index table down to 8^3 cells + occupancy
+ *    blocks of the lowest three levels, trace_svo_blocks), 0 = through the node chain below the table (trees of
+ *    fewer than 3 or more than 11 levels, res not a multiple of 8, nodes not in breadth-first order, stored nodes
+ *    without children; wavefronts holding an irregular ray take the node chain whatever the tree). */
 int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
 
 /* Sky tiles (no reference counterpart: the reference traces every pixel, main.cpp:252-287).  For one
@@ -255,7 +261,9 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
  * frame's sub-rectangle -- OUTSIDE of which every ray provably ends both passes at its first bounds
  * test (0 steps, no hit, depth +inf, pixel 255,0,0,0).  8x8 tiles that lie wholly outside it write
  * those values without setting their rays up, unless pt_end is requested.  The rectangle is the
- * bounding box of the projected corners of both grids, widened by one cell and four pixels; it is
+ * bounding box of the projected corners of both grids, widened by one cell and by four pixels plus three times
+ * the bound on the drift of the reference's serial direction sums (it grows with the frame: 3 px more at 4K, 10 at
+ * 7680x4320); it is
  * the whole sub-rectangle (no cull) when a corner is beside or behind the camera, for
  * VOLLY_FRAME_RAYTRACE frames, and in beam mode when the frame's low and target constants do not
  * describe the same rays.  x_lo > x_hi or y_lo > y_hi: nothing can be hit.  VOLLY_SKY_CULL=0 in the

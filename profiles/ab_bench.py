@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--mode", default="beam")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--views", type=int, default=None)
+    ap.add_argument("--camera", choices=["orbit", "startup", "inside", "fill"], default="orbit", help="bench.py's camera regimes")
     ap.add_argument("--planes", default="rgba8,hit_index,steps_lo,steps_hi,depth", help="output planes written in the timed runs")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
@@ -43,8 +44,16 @@ def main():
     scene = None
     if p["scene"] != "noise":
         scene = vra.HostScene.from_mesh(os.path.join(ROOT, "assets", p["scene"]), res, dense=dense, svo=not dense)
-    frames = [vra.orbit_frames([(s * nv + i) % 4096 for i in range(nv)], 4096, (res,) * 3, (res // 4,) * 3, W, H,
-                               radius=p["radius"], naive=a.mode == "naive") for s in range(3)]
+    if a.camera == "startup":
+        view = vra.look_at((0, 0, 0), vra.host.cam_dir_from_mouse(0, 0), (0, 0, -1))
+        one = (vra.FrameDesc * nv)()
+        for i in range(nv):
+            one[i] = vra.frame_from_camera(view, (0.0, 0.0, 0.0), (res,) * 3, (res // 4,) * 3, W, H, naive=a.mode == "naive")
+        frames = [one] * 3
+    else:
+        radius = B.CAMERA_RADIUS.get(a.camera, p["radius"])
+        frames = [vra.orbit_frames([(s * nv + i) % 4096 for i in range(nv)], 4096, (res,) * 3, (res // 4,) * 3, W, H,
+                                   radius=radius, naive=a.mode == "naive") for s in range(3)]
     dev = torch.device("cuda:0")
     planes = {q: torch.empty((nv, H, W), dtype=torch.float32 if q == "depth" else torch.int32, device=dev)
               for q in ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")}

@@ -222,7 +222,8 @@ void choose_frame_kernel(volly_gpu_scene *s)
     s->requeue = rq && !s->refill;
 }
 
-int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res)
+int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res,
+               int64_t l3_first, int64_t l3_count)
 {
     s->is_svo = true;
     s->svo.nodes = nodes; s->svo.leaves = leaves;
@@ -231,8 +232,10 @@ int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes
     s->svo.depth = depth; s->svo.res = res; s->svo.fres = (float)res;
     s->svo.cap = 4u * (uint32_t)(3 * res) + 8u;
     s->target.sx = s->target.sy = s->target.sz = res;
-    // direct-index table of the upper levels: cells of 2^tshift voxels, at most 128^3 entries
-    int tbits = std::min(std::max(depth - 3, 0), 7);
+    // direct-index table of the upper levels: cells of 2^tshift voxels.  Down to 8^3 cells (tshift = 3) for trees
+    // of up to 2048^3 (256^3 entries, 64 MiB), where the occupancy blocks take over; at most 128^3 entries above that
+    int tbits = std::max(depth - 3, 0);
+    if (tbits > 8) tbits = 7;
     if (const char *e = std::getenv("VOLLY_SVO_TABLE_BITS")) tbits = std::min(std::max(std::atoi(e), 0), std::min(depth - 1, 8));
     s->svo.tbits = tbits;
     s->svo.tshift = depth - tbits;
@@ -243,6 +246,25 @@ int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes
     hipLaunchKernelGGL(vk::build_svo_table, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, nodes, depth, tbits, s->svo.tshift, table);
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(VOLLY_E_HIP, "build_svo_table failed");
     s->svo.table = table;
+    // occupancy blocks of the lowest three levels (vk::build_svo_blocks): needs the level-3 nodes as one contiguous
+    // index range (breadth-first trees have that; the caller says where), table cells of 8^3 and whole 8^3 cells
+    // inside the grid.  VOLLY_SVO_BLOCKS=0 keeps the node-chain traversal (A/B runs).
+    s->svo.blocks = nullptr; s->svo.l3_first = 0; s->svo.use_blocks = 0;
+    bool want = depth >= 3 && s->svo.tshift == 3 && (res & 7) == 0 && l3_first >= 0 && l3_count > 0 && l3_first + l3_count <= (int64_t)n_nodes;
+    if (const char *e = std::getenv("VOLLY_SVO_BLOCKS")) want = want && std::atoi(e) != 0;
+    if (want) {
+        uint64_t *blocks = nullptr;
+        if ((rc = dev_alloc(s, (void **)&blocks, (size_t)l3_count * 64 + 8))) return rc;
+        uint32_t *bad = (uint32_t *)(blocks + (size_t)l3_count * 8);
+        HIP_TRY(hipMemset(bad, 0, 8));
+        hipLaunchKernelGGL(vk::build_svo_blocks, dim3((unsigned)((l3_count + 255) / 256)), dim3(256), 0, 0, nodes, (uint32_t)l3_first, (uint32_t)l3_count, blocks, bad);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(VOLLY_E_HIP, "build_svo_blocks failed");
+        uint32_t is_bad = 1;
+        HIP_TRY(hipMemcpy(&is_bad, bad, 4, hipMemcpyDeviceToHost));
+        s->svo.blocks = blocks;
+        s->svo.l3_first = (uint32_t)l3_first;
+        s->svo.use_blocks = is_bad ? 0 : 1;      // a stored node without children: the node chain decides (see build_svo_blocks)
+    }
     return VOLLY_OK;
 }
 
@@ -671,6 +693,7 @@ int svo_gpu_upload(int device, const volly_svo_desc *svo, const volly_dense_desc
     // The kernel trusts the tree: check that every child reference stays inside the
     // arrays, points forward (breadth-first order) and that leaves sit exactly at
     // level 1, so a walk from the root ends after at most `depth` nodes.
+    int64_t l3_first = -1, l3_count = 0;                 // the level-3 nodes (8^3 cells), if they form one index range
     {
         const volly_svo_node *nd = svo->nodes;
         std::vector<int8_t> level(svo->n_nodes, (int8_t)-1);
@@ -690,6 +713,10 @@ int svo_gpu_upload(int device, const volly_svo_desc *svo, const volly_dense_desc
                 for (uint32_t c = 0; c < cnt; ++c) level[nd[i].child_offset + c] = (int8_t)(level[i] - 1);
             }
         }
+        int64_t l3_last = -1;
+        for (uint32_t i = 0; i < svo->n_nodes; ++i)
+            if (level[i] == 3) { if (l3_first < 0) l3_first = i; l3_last = i; ++l3_count; }
+        if (l3_count && l3_last - l3_first + 1 != l3_count) l3_first = -1;      // not breadth first: no blocks
     }
     int rc;
     if (low && (rc = check_dense(low, "svo_gpu_upload low"))) return rc;
@@ -705,7 +732,7 @@ int svo_gpu_upload(int device, const volly_svo_desc *svo, const volly_dense_desc
         rc = fail(VOLLY_E_HIP, "svo_gpu_upload: node copy failed");
     if (!rc && svo->n_leaves && hipMemcpy(leaves, svo->leaves, (size_t)svo->n_leaves * 8, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(VOLLY_E_HIP, "svo_gpu_upload: leaf copy failed");
-    if (!rc) rc = finish_svo(s, nodes, leaves, svo->n_nodes, (uint32_t)svo->n_leaves, svo->depth, svo->res);
+    if (!rc) rc = finish_svo(s, nodes, leaves, svo->n_nodes, (uint32_t)svo->n_leaves, svo->depth, svo->res, l3_first, l3_count);
     if (!rc && low) {
         rc = make_dense(s, low->sx, low->sy, low->sz, low->voxels, nullptr, &s->low);
         s->has_low = true;
@@ -1012,6 +1039,7 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 13: return s->target.vox != nullptr;
     case 14: return s->is_svo ? 0 : dda_loop_of(s->target);
     case 15: return s->has_low ? dda_loop_of(s->low) : 0;
+    case 16: return s->is_svo ? s->svo.use_blocks : 0;
     default: return -1;
     }
 }

@@ -85,8 +85,10 @@ int dev_alloc(volly_gpu_scene *s, void **p, size_t bytes);
 void adopt(volly_gpu_scene *s, void *p, size_t bytes);
 // upload (host_vox) or adopt (dev_vox, already owned by the scene) the 8-byte voxels of one grid and derive its occupancy levels
 int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox, uint2 *dev_vox, vk::DenseDev *out);
-// describe a device-resident octree (arrays already owned by the scene) and build its direct-index table
-int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res);
+// describe a device-resident octree (arrays already owned by the scene), build its direct-index table and, when the
+// level-3 nodes are the index range [l3_first, l3_first + l3_count) (l3_first < 0: unknown), its occupancy blocks
+int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res,
+               int64_t l3_first, int64_t l3_count);
 void choose_frame_kernel(volly_gpu_scene *s);
 
 } // namespace vimpl

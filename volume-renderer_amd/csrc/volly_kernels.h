@@ -34,6 +34,7 @@
 //   VK_OCC_LEVELS=1   one occupancy level (4^3 bricks) instead of two (bricks + 16^3 regions)
 //   VK_SVO_TABLE=0    locate octree cells by walking down from the root instead of starting at
 //                     the direct-index table of the upper levels
+//   VK_SVO_BLOCKS=0   no occupancy blocks for the lowest three octree levels: every locate walks the node chain
 //   VK_CKPT_STRIDE=4  a direction checkpoint every 4 pixels instead of 8 (at most 3 instead of 7
 //                     serial adds per lane and component, twice the checkpoint traffic: measured
 //                     1.4 % slower on config 2, 4 % on config 1)
@@ -64,6 +65,9 @@
 #endif
 #ifndef VK_SVO_TABLE
 #define VK_SVO_TABLE 1              // 0: walk down from the root at every iteration
+#endif
+#ifndef VK_SVO_BLOCKS
+#define VK_SVO_BLOCKS VK_SVO_TABLE  // 0: locate every cell through the node chain below the table (trace_svo only)
 #endif
 #ifndef VK_WAVE_BLOCK
 #define VK_WAVE_BLOCK 1
@@ -131,6 +135,10 @@ struct SvoDev {
     const uint2 *nodes;             // .x = child_offset, .y = valid_mask | leaf_mask<<8
     const uint2 *leaves;
     const uint32_t *table;          // upper levels flattened: (2^tbits)^3 entries, see build_svo_table
+    const uint64_t *blocks;         // lowest three levels flattened: 8 occupancy words (one per 4^3 octant, the dense bricks' bit
+                                    // order) per level-3 node (an 8^3 cell), indexed by node - l3_first; see build_svo_blocks
+    uint32_t l3_first;              // index of the first level-3 node (breadth-first order: the nodes of a level are contiguous)
+    int use_blocks;                 // the table ends at 8^3 cells (tshift == 3), blocks are built, res is a multiple of 8: trace_svo_blocks
     int tbits, tshift;              // table cell = octree cell of 2^tshift voxels; tbits + tshift = depth
     uint32_t n_nodes;
     int depth, res;
@@ -908,7 +916,7 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const Ray &r, float ox
         uint2 n = entry_node;
         sh = t.tshift - 1;
         if (entry >> 31) {
-            sh = (int)(entry & 31u);                      // empty cell of 2^sh voxels, above the table's level
+            sh = (int)((entry >> 23) & 0xFFu) - 127;      // empty cell of 2^sh voxels, above the table's level: the entry is -(2^sh) as a float
         } else
 #else
         uint2 n = t.nodes[0];
@@ -935,6 +943,103 @@ __device__ __forceinline__ Hit trace_svo(const SvoDev &t, const Ray &r, float ox
         float s = __uint_as_float((uint32_t)(127 + sh) << 23);
         float is = __uint_as_float((uint32_t)(127 - sh) << 23);
         advance_cell(r, s, is, px, py, pz, h.cx, h.cy, h.cz);
+    }
+    return h;
+}
+
+// The same step with the three multiplications by s folded into one: floor(p/s)*s + h*s == (floor(p/s) + h)*s bit
+// for bit -- floor(p/s) is an integer of magnitude <= 2^13, h is 0 or 1, s a power of two, so both sides are the
+// exact product (no rounding happens on either side; -0 + 0 and -s + s are +0 on both).
+__device__ __forceinline__ void advance_cell_folded(const Ray &r, float s, float is, float px, float py, float pz,
+                                                    float &cx, float &cy, float &cz)
+{
+    float ndx = (((floorf(px * is) + r.hx) * s) - cx) * r.ix;
+    float ndy = (((floorf(py * is) + r.hy) * s) - cy) * r.iy;
+    float ndz = (((floorf(pz * is) + r.hz) * s) - cz) * r.iz;
+    float m = fminf(fminf(ndx, ndy), ndz);
+    cx = m * r.dx + cx;
+    cy = m * r.dy + cy;
+    cz = m * r.dz + cz;
+}
+
+__device__ __forceinline__ bool svo_is_regular(const SvoDev &t) { return t.use_blocks != 0; }
+
+// Octree traversal over the flattened tree (VK_SVO_BLOCKS): the same iterations as trace_svo -- every decision and
+// every float equal -- with at most two dependent loads per iteration instead of up to five, and most iterations none:
+//   * upper levels: the direct-index table gives, per 8^3 cell, "empty cell of 2^k voxels" (as the float -(2^k)) or
+//     the level-3 node that covers it; a lane keeps that entry while its sample cell stays in the 8^3 cell;
+//   * lowest three levels: the node's block holds one 64-bit occupancy word per 4^3 octant.  word == 0: the octant is
+//     an empty cell of 4 voxels; the 2^3 sub-octant's eight bits clear: an empty cell of 2; else the voxel's own bit
+//     decides between a hit and an empty cell of 1.  A lane keeps the word while it stays in the 4^3 brick.
+// The leaf index of a hit is found afterwards by one walk down from the level-3 node (three loads per hit ray).
+// Preconditions (svo_is_regular + regular rays, checked by the caller): res a multiple of 8 (so a cell outside the
+// grid never shares its 8^3 key with the cell before it), table cells of 8^3, every direction component regular.
+// Cells are kept as the pair xy = x | y << 16 (saturating conversion: a negative or huge coordinate becomes 0xffff,
+// which no key inside a grid of <= 2048 has) and z.
+__device__ __forceinline__ Hit trace_svo_blocks(const SvoDev &t, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, t.fres, t.fres, t.fres, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
+    const uint32_t res = (uint32_t)t.res;
+    uint32_t key_xy = 0xFFFFFFFFu, key_z = 0xFFFFFFFFu;  // the 8^3 cell the cached entry belongs to
+    uint32_t l3 = 0;                                     // sign bit: empty cell of -l3 voxels (a float); else level-3 node index
+    uint32_t bkey_xy = 0xFFFFFFFFu, bkey_z = 0xFFFFFFFFu; // the 4^3 brick the cached word belongs to
+    uint32_t w_lo = 0, w_hi = 0;
+    bool hit = false;
+    int x = 0, y = 0, z = 0;
+    for (;;) {
+        float px = h.cx + r.ex, py = h.cy + r.ey, pz = h.cz + r.ez;
+        x = (int)px; y = (int)py; z = (int)pz;           // truncation toward zero, saturating
+        if (h.steps >= t.cap) break;
+        const uint32_t k_xy = ((uint32_t)x & 0xFFF8u) | (((uint32_t)y & 0xFFF8u) << 16), k_z = (uint32_t)z & 0xFFFFFFF8u;
+        const bool oob16 = ((uint32_t)x > 0xFFFFu) | ((uint32_t)y > 0xFFFFu);       // what the saturating pack turns into 0xffff
+        if (oob16 | (k_xy != key_xy) | (k_z != key_z)) {
+            if (!(((uint32_t)x < res) & ((uint32_t)y < res) & ((uint32_t)z < res))) break;   // main.cpp:126-135
+            key_xy = k_xy; key_z = k_z;
+            l3 = t.table[((uint32_t)x >> 3) | (((uint32_t)y >> 3) << t.tbits) | (((uint32_t)z >> 3) << (2 * t.tbits))];
+        }
+        ++h.steps;
+        float s;
+        if (l3 >> 31) {
+            s = __uint_as_float(l3 & 0x7FFFFFFFu);
+        } else {
+            const uint32_t b_xy = ((uint32_t)x & 0xFFFCu) | (((uint32_t)y & 0xFFFCu) << 16), b_z = (uint32_t)z & 0xFFFFFFFCu;
+            if ((b_xy != bkey_xy) | (b_z != bkey_z)) {
+                bkey_xy = b_xy; bkey_z = b_z;
+                const uint32_t o4 = (((uint32_t)x >> 2) & 1u) | ((((uint32_t)y >> 2) & 1u) << 1) | ((((uint32_t)z >> 2) & 1u) << 2);
+                const uint64_t w = t.blocks[(size_t)(l3 - t.l3_first) * 8 + o4];
+                w_lo = (uint32_t)w; w_hi = (uint32_t)(w >> 32);
+            }
+            if ((w_lo | w_hi) == 0u) {
+                s = 4.0f;
+            } else {
+                const uint32_t b = ((uint32_t)x & 3u) | (((uint32_t)y & 3u) << 2) | (((uint32_t)z & 3u) << 4);
+                const uint64_t w = ((uint64_t)w_hi << 32) | w_lo;
+                const uint32_t oct = (uint32_t)(w >> (b & 0x2Au));          // the 2^3 sub-octant's bits at offsets 0,1,4,5,16,17,20,21
+                if ((oct & 0x00330033u) == 0u) s = 2.0f;
+                else if ((oct >> (b & 0x15u)) & 1u) { hit = true; break; }  // leaf voxel
+                else s = 1.0f;
+            }
+        }
+        const float is = __uint_as_float(0x7F000000u - __float_as_uint(s));  // 2^-k for s = 2^k
+        advance_cell_folded(r, s, is, px, py, pz, h.cx, h.cy, h.cz);
+    }
+    if (hit) {
+        h.index = (uint32_t)x + res * ((uint32_t)y + res * (uint32_t)z);
+        uint2 n = t.nodes[l3];
+        uint32_t child = 0;
+        #pragma unroll
+        for (int sh = 2; sh >= 0; --sh) {
+            const uint32_t oct = (((uint32_t)x >> sh) & 1u) | ((((uint32_t)y >> sh) & 1u) << 1) | ((((uint32_t)z >> sh) & 1u) << 2);
+            const uint32_t valid = n.y & 0xFFu, bit = 1u << oct;
+            child = n.x + (uint32_t)__popc(valid & (bit - 1u));
+            if (sh) n = t.nodes[child];
+        }
+        h.payload = child;
     }
     return h;
 }
@@ -1243,7 +1348,16 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
         sx = fd.scale_lo_to_hi[0] * lo.cx; sy = fd.scale_lo_to_hi[1] * lo.cy; sz = fd.scale_lo_to_hi[2] * lo.cz;
     }
 
-    Hit hi = SVO ? trace_svo(svo, ray_hi, sx, sy, sz) : trace_dense(target, ray_hi, sx, sy, sz);
+    Hit hi;
+    if constexpr (SVO) {
+#if VK_SVO_BLOCKS
+        // one path per wavefront, as in trace_dense
+        if (svo_is_regular(svo) && __all(ray_is_regular(ray_hi))) hi = trace_svo_blocks(svo, ray_hi, sx, sy, sz);
+        else
+#endif
+            hi = trace_svo(svo, ray_hi, sx, sy, sz);
+    } else
+        hi = trace_dense(target, ray_hi, sx, sy, sz);
     o.shi = hi.steps;
     o.hit = hi.index;
     o.ex = hi.cx; o.ey = hi.cy; o.ez = hi.cz;
@@ -1393,8 +1507,9 @@ __global__ void __launch_bounds__(256) build_region_cubes(const uint64_t *occ2, 
 }
 
 // Upper octree levels as a direct-index table: entry (tx,ty,tz) describes the octree cell
-// of 2^tshift voxels at (tx,ty,tz) << tshift: the index of the node covering it, or
-// 0x80000000 | k when the walk from the root ends earlier in an empty cell of 2^k voxels.
+// of 2^tshift voxels at (tx,ty,tz) << tshift: the index of the node covering it, or, when the
+// walk from the root ends earlier in an empty cell of 2^k voxels, the float -(2^k) (sign bit = empty;
+// its magnitude is the step's cell size as the advance uses it).
 __global__ void __launch_bounds__(256) build_svo_table(const uint2 *nodes, int depth, int tbits, int tshift, uint32_t *table)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1408,10 +1523,45 @@ __global__ void __launch_bounds__(256) build_svo_table(const uint2 *nodes, int d
         const uint2 nd = nodes[node];
         const uint32_t oct = ((x >> sh) & 1u) | (((y >> sh) & 1u) << 1) | (((z >> sh) & 1u) << 2);
         const uint32_t valid = nd.y & 0xFFu, bit = 1u << oct;
-        if (!(valid & bit)) { entry = 0x80000000u | (uint32_t)sh; done = true; break; }
+        if (!(valid & bit)) { entry = 0x80000000u | ((uint32_t)(127 + sh) << 23); done = true; break; }
         node = nd.x + (uint32_t)__popc(valid & (bit - 1u));
     }
     table[i] = done ? entry : node;
+}
+
+// Lowest three octree levels as occupancy blocks: for the level-3 node l3_first + j (an 8^3 cell) eight words, one
+// per 4^3 octant in octant order, bit x&3 | (y&3)<<2 | (z&3)<<4 set iff that voxel is a leaf -- the dense bricks'
+// layout.  A word is zero exactly when the octant's valid bit is clear, PROVIDED no stored node is empty; a valid
+// child without children would end the oracle's walk one level further down (a smaller empty cell), so such a
+// tree sets *bad and keeps the node-chain traversal.
+__global__ void __launch_bounds__(256) build_svo_blocks(const uint2 *nodes, uint32_t l3_first, uint32_t l3_count, uint64_t *blocks, uint32_t *bad)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= l3_count) return;
+    const uint2 n3 = nodes[l3_first + j];
+    const uint32_t valid3 = n3.y & 0xFFu;
+    if ((n3.y >> 8) & 0xFFu) *bad = 1u;                                  // leaves above level 1
+    for (uint32_t o4 = 0; o4 < 8; ++o4) {
+        uint64_t word = 0;
+        if (valid3 & (1u << o4)) {
+            const uint2 n2 = nodes[n3.x + (uint32_t)__popc(valid3 & ((1u << o4) - 1u))];
+            const uint32_t valid2 = n2.y & 0xFFu;
+            if (!valid2 || ((n2.y >> 8) & 0xFFu)) *bad = 1u;
+            for (uint32_t o2 = 0; o2 < 8; ++o2) {
+                if (!(valid2 & (1u << o2))) continue;
+                const uint2 n1 = nodes[n2.x + (uint32_t)__popc(valid2 & ((1u << o2) - 1u))];
+                const uint32_t leaf = (n1.y >> 8) & 0xFFu;
+                if (!leaf || leaf != (n1.y & 0xFFu)) *bad = 1u;
+                for (uint32_t o1 = 0; o1 < 8; ++o1) {
+                    if (!(leaf & (1u << o1))) continue;
+                    const uint32_t x = ((o2 & 1u) << 1) | (o1 & 1u), y = (((o2 >> 1) & 1u) << 1) | ((o1 >> 1) & 1u),
+                                   z = (((o2 >> 2) & 1u) << 1) | ((o1 >> 2) & 1u);
+                    word |= 1ull << (x | (y << 2) | (z << 4));
+                }
+            }
+        }
+        blocks[(size_t)j * 8 + o4] = word;
+    }
 }
 
 // synthetic noise voxels (volume_gpu_generate_noise)

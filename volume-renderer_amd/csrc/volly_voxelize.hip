@@ -767,7 +767,9 @@ int build_octree(volly_gpu_scene *s, const uint64_t *words, uint64_t n_words, in
     }
     HIP_TRY(hipDeviceSynchronize());
     sc.sub(n_words * 24);
-    return finish_svo(s, nodes, leaves, (uint32_t)at, (uint32_t)n_leaves, depth, res);
+    // the levels were written one after the other: level 3 is the index range base[3] .. base[3] + level[3].n
+    const bool has_l3 = depth >= 3 && !empty;
+    return finish_svo(s, nodes, leaves, (uint32_t)at, (uint32_t)n_leaves, depth, res, has_l3 ? (int64_t)base[3] : -1, has_l3 ? (int64_t)level[3].n : 0);
 }
 
 // The search and its reduction to LoD 0: sorted (cell, last triangle) words
