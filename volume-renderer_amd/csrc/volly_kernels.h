@@ -34,6 +34,7 @@
 //   VK_OCC_LEVELS=1   one occupancy level (4^3 bricks) instead of two (bricks + 16^3 regions)
 //   VK_SVO_TABLE=0    locate octree cells by walking down from the root instead of starting at
 //                     the direct-index table of the upper levels
+//   VK_ASM_SVO=0      the compiled loop over the flattened octree (trace_svo_blocks)
 //   VK_SVO_BLOCKS=0   no occupancy blocks for the lowest three octree levels: every locate walks the node chain
 //   VK_CKPT_STRIDE=4  a direction checkpoint every 4 pixels instead of 8 (at most 3 instead of 7
 //                     serial adds per lane and component, twice the checkpoint traffic: measured
@@ -1044,6 +1045,206 @@ __device__ __forceinline__ Hit trace_svo_blocks(const SvoDev &t, const Ray &r, f
     return h;
 }
 
+// trace_svo_blocks in assembly, with nothing left to compiled code (VK_ASM_SVO).  The compiled loop spends ~90 vector
+// and ~80 scalar instructions per wave-iteration, most of the scalar ones exec-mask bookkeeping of its nested
+// per-lane tests (profiles/r02: 726 M scalar beside 989 M vector instructions per launch of the naive headline: the CU's
+// shared scalar pipe is as busy as its four vector pipes).  Here an iteration is 38 vector + ~12 scalar instructions
+// while every live lane sits in an empty cell above the blocks' level, 58 + ~25 with lanes inside 8^3 cells that hold
+// voxels -- the wave-coherent skips the north star asks for are the scalar branches below: a wavefront whose lanes
+// all kept their 8^3 cell skips the table block, one whose lanes are all in empty upper-level cells skips the block /
+// brick tests altogether (s_cbranch_vccz on the ballot of "my entry is a node").
+//   exec = live lanes; m0 = iteration number = samples taken so far (the lane's step count when it leaves).
+//   v47-v49 sample point, v50-v52 cell, v56 = x | y << 16 (saturating pack: a coordinate outside [0, 65535] gives 0xffff,
+//   which no key of a grid <= 2048 has), v57 table entry (sign set: -(cell size) of an empty cell; else the level-3 node),
+//   v58:v59 key of the 8^3 cell it belongs to (xy, z), v60:v61 key of the 4^3 brick whose word is in v44:v45,
+//   v62 / v63 the step's cell size s and 1/s, v46 and v53-v55 temporaries.
+// Results: steps (0xffffffff: still live at the cap) and hitl3 (the level-3 node of a hit, 0xffffffff: no hit); the
+// hit cell is recomputed afterwards from cur, which a finished lane no longer changes.
+#ifndef VK_ASM_SVO
+#define VK_ASM_SVO 1
+#endif
+__device__ __forceinline__ Hit trace_svo_blocks_asm(const SvoDev &t, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, t.fres, t.fres, t.fres, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
+    const uint32_t cap = t.cap, res = (uint32_t)t.res, tbits = (uint32_t)t.tbits, l3_first = t.l3_first;
+    const uint32_t *table = t.table;
+    const uint64_t *blocks = t.blocks;
+    uint32_t steps = 0xFFFFFFFFu;                         // still live
+    uint32_t hitl3 = 0xFFFFFFFFu;                         // level-3 node of the hit
+    uint64_t mask_e, mask_a, mask_b, mask_c;
+    uint32_t tmp;
+    asm volatile(
+        "s_mov_b64 %[se], exec\n\t"
+        "s_mov_b32 m0, 0\n\t"
+        "v_mov_b32 v58, -1\n\t"                       // no 8^3 cell yet (a key no cell has)
+        "v_mov_b32 v59, -1\n\t"
+        "v_mov_b32 v60, -1\n\t"                       // no brick yet
+        "v_mov_b32 v61, -1\n\t"
+        "v_mov_b32 v57, 0\n\t"
+        "v_mov_b32 v44, 0\n\t"
+        "v_mov_b32 v45, 0\n"
+        "1:\n\t"                                      // ---- sample point, cell, 8^3 key (exec = live lanes)
+        "v_add_f32 v47, %[cx], %[ex]\n\t"
+        "v_add_f32 v48, %[cy], %[ey]\n\t"
+        "v_add_f32 v49, %[cz], %[ez]\n\t"
+        "v_cvt_i32_f32 v50, v47\n\t"
+        "v_cvt_i32_f32 v51, v48\n\t"
+        "v_cvt_i32_f32 v52, v49\n\t"
+        "v_cvt_pk_u16_u32 v56, v50, v51\n\t"
+        "s_cmp_ge_u32 m0, %[cap]\n\t"
+        "s_cbranch_scc1 9f\n\t"
+        "v_and_b32 v54, 0xfff8fff8, v56\n\t"
+        "v_and_b32 v55, -8, v52\n\t"
+        "v_cmp_ne_u64 vcc, v[54:55], v[58:59]\n\t"
+        "s_cbranch_vccz 4f\n\t"
+        "s_mov_b64 %[sa], exec\n\t"                   // sa: the live lanes
+        "s_mov_b64 exec, vcc\n\t"                     // ---- lanes in a new 8^3 cell: bounds test (main.cpp:126-135), table entry
+        "v_cmp_gt_u32 vcc, %[res], v50\n\t"
+        "v_cmp_gt_u32 %[sc], %[res], v51\n\t"
+        "s_and_b64 vcc, vcc, %[sc]\n\t"
+        "v_cmp_gt_u32 %[sc], %[res], v52\n\t"
+        "s_and_b64 vcc, vcc, %[sc]\n\t"               // vcc: inside the grid
+        "s_andn2_b64 %[sc], exec, vcc\n\t"            // sc: outside
+        "s_cbranch_scc0 2f\n\t"
+        "s_mov_b64 exec, %[sc]\n\t"
+        "s_mov_b32 %[tmp], m0\n\t"
+        "v_mov_b32 %[steps], %[tmp]\n\t"
+        "s_andn2_b64 %[sa], %[sa], %[sc]\n"           // no longer live
+        "2:\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "s_lshl_b32 %[tmp], %[tbits], 1\n\t"
+        "v_lshrrev_b32 v53, 3, v50\n\t"               // table index x>>3 | (y>>3) << tbits | (z>>3) << 2 tbits
+        "v_lshrrev_b32 v46, 3, v51\n\t"
+        "v_lshl_or_b32 v53, v46, %[tbits], v53\n\t"
+        "v_lshrrev_b32 v46, 3, v52\n\t"
+        "v_lshl_or_b32 v53, v46, %[tmp], v53\n\t"
+        "v_lshlrev_b32 v53, 2, v53\n\t"
+        "global_load_dword v57, v53, %[table]\n\t"
+        "v_mov_b32 v58, v54\n\t"
+        "v_mov_b32 v59, v55\n\t"
+        "s_waitcnt vmcnt(0)\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[sa]\n\t"
+        "s_cbranch_execz 9f\n"
+        "4:\n\t"                                      // ---- the cell size of an empty upper-level cell; which lanes sit in a cell with voxels
+        "v_and_b32 v62, 0x7fffffff, v57\n\t"
+        "v_cmp_le_i32 vcc, 0, v57\n\t"
+        "s_cbranch_vccz 8f\n\t"                       // every live lane is in an empty cell of >= 8 voxels: straight to the step
+        "s_mov_b64 %[sa], exec\n\t"
+        "s_mov_b64 exec, vcc\n\t"                     // ---- lanes in an 8^3 cell that holds voxels: the 4^3 brick's word
+        "v_and_b32 v54, 0xfffcfffc, v56\n\t"
+        "v_and_b32 v55, -4, v52\n\t"
+        "v_cmp_ne_u64 vcc, v[54:55], v[60:61]\n\t"
+        "s_and_saveexec_b64 %[sb], vcc\n\t"           // sb: lanes at a node; exec: those that need the word
+        "s_cbranch_execz 5f\n\t"
+        "v_sub_u32 v53, v57, %[l3f]\n\t"              // byte offset 64 * (node - l3_first) + 8 * octant
+        "v_lshlrev_b32 v53, 6, v53\n\t"
+        "v_bfe_u32 v46, v50, 2, 1\n\t"
+        "v_lshl_or_b32 v53, v46, 3, v53\n\t"
+        "v_bfe_u32 v46, v51, 2, 1\n\t"
+        "v_lshl_or_b32 v53, v46, 4, v53\n\t"
+        "v_bfe_u32 v46, v52, 2, 1\n\t"
+        "v_lshl_or_b32 v53, v46, 5, v53\n\t"
+        "global_load_dwordx2 v[44:45], v53, %[blocks]\n\t"
+        "v_mov_b32 v60, v54\n\t"
+        "v_mov_b32 v61, v55\n\t"
+        "s_waitcnt vmcnt(0)\n"
+        "5:\n\t"
+        "s_mov_b64 exec, %[sb]\n\t"
+        "v_mov_b32 v62, 4.0\n\t"                      // an empty 4^3 octant unless the word has bits
+        "v_cmp_ne_u64 vcc, 0, v[44:45]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 7f\n\t"
+        "v_and_b32 v53, 3, v50\n\t"                   // bit index x&3 | (y&3)<<2 | (z&3)<<4
+        "v_and_b32 v54, 3, v51\n\t"
+        "v_lshl_or_b32 v53, v54, 2, v53\n\t"
+        "v_and_b32 v54, 3, v52\n\t"
+        "v_lshl_or_b32 v53, v54, 4, v53\n\t"
+        "v_and_b32 v54, 0x2a, v53\n\t"                // the 2^3 sub-octant's first bit
+        "v_lshrrev_b64 v[54:55], v54, v[44:45]\n\t"
+        "v_and_b32 v55, 0x330033, v54\n\t"            // its eight voxels: offsets 0,1,4,5,16,17,20,21
+        "v_mov_b32 v62, 2.0\n\t"
+        "v_cmp_ne_u32 vcc, 0, v55\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 7f\n\t"
+        "v_and_b32 v53, 0x15, v53\n\t"                // the voxel's own bit
+        "v_bfe_u32 v54, v54, v53, 1\n\t"
+        "v_mov_b32 v62, 1.0\n\t"
+        "v_cmp_eq_u32 vcc, 1, v54\n\t"
+        "s_cbranch_vccz 7f\n\t"
+        "s_mov_b64 exec, vcc\n\t"                     // ---- hits
+        "s_add_u32 %[tmp], m0, 1\n\t"
+        "v_mov_b32 %[steps], %[tmp]\n\t"
+        "v_mov_b32 %[hitl3], v57\n\t"
+        "s_andn2_b64 %[sa], %[sa], vcc\n"
+        "7:\n\t"
+        "s_mov_b64 exec, %[sa]\n\t"
+        "s_cbranch_execz 9f\n"
+        "8:\n\t"                                      // ---- the step across the empty cell of s voxels (advance_cell_folded)
+        "v_sub_u32 v63, 0x7f000000, v62\n\t"          // 1/s
+        "v_mul_f32 v53, v47, v63\n\t"
+        "v_mul_f32 v54, v48, v63\n\t"
+        "v_mul_f32 v55, v49, v63\n\t"
+        "v_floor_f32 v53, v53\n\t"
+        "v_floor_f32 v54, v54\n\t"
+        "v_floor_f32 v55, v55\n\t"
+        "v_add_f32 v53, v53, %[hx]\n\t"
+        "v_add_f32 v54, v54, %[hy]\n\t"
+        "v_add_f32 v55, v55, %[hz]\n\t"
+        "v_mul_f32 v53, v53, v62\n\t"
+        "v_mul_f32 v54, v54, v62\n\t"
+        "v_mul_f32 v55, v55, v62\n\t"
+        "v_sub_f32 v53, v53, %[cx]\n\t"
+        "v_sub_f32 v54, v54, %[cy]\n\t"
+        "v_sub_f32 v55, v55, %[cz]\n\t"
+        "v_mul_f32 v53, v53, %[ix]\n\t"
+        "v_mul_f32 v54, v54, %[iy]\n\t"
+        "v_mul_f32 v55, v55, %[iz]\n\t"
+        "v_min3_f32 v53, v53, v54, v55\n\t"
+        "v_mul_f32 v54, v53, %[dx]\n\t"
+        "v_mul_f32 v55, v53, %[dy]\n\t"
+        "v_mul_f32 v53, v53, %[dz]\n\t"
+        "v_add_f32 %[cx], v54, %[cx]\n\t"
+        "v_add_f32 %[cy], v55, %[cy]\n\t"
+        "v_add_f32 %[cz], v53, %[cz]\n\t"
+        "s_add_u32 m0, m0, 1\n\t"
+        "s_branch 1b\n"
+        "9:\n\t"
+        "s_mov_b64 exec, %[se]"
+        : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [steps] "+v"(steps), [hitl3] "+v"(hitl3),
+          [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sb] "=&s"(mask_b), [sc] "=&s"(mask_c), [tmp] "=&s"(tmp)
+        : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
+          [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
+          [cap] "s"(cap), [res] "s"(res), [tbits] "s"(tbits), [l3f] "s"(l3_first), [table] "s"(table), [blocks] "s"(blocks)
+        : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59",
+          "v60", "v61", "v62", "v63");
+    uint32_t iter;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
+    h.steps = (steps == 0xFFFFFFFFu) ? iter : steps;     // lanes still live left at the iteration cap
+    if (hitl3 != 0xFFFFFFFFu) {
+        // the hit cell again from cur, which the lane has not changed since (the same two operations the loop did)
+        const uint32_t x = (uint32_t)(int)(h.cx + r.ex), y = (uint32_t)(int)(h.cy + r.ey), z = (uint32_t)(int)(h.cz + r.ez);
+        h.index = x + res * (y + res * z);
+        uint2 n = t.nodes[hitl3];
+        uint32_t child = 0;
+        #pragma unroll
+        for (int sh = 2; sh >= 0; --sh) {
+            const uint32_t oct = ((x >> sh) & 1u) | (((y >> sh) & 1u) << 1) | (((z >> sh) & 1u) << 2);
+            const uint32_t valid = n.y & 0xFFu, bit = 1u << oct;
+            child = n.x + (uint32_t)__popc(valid & (bit - 1u));
+            if (sh) n = t.nodes[child];
+        }
+        h.payload = child;
+    }
+    return h;
+}
+
 // glm::normalize(vec4(x,y,z,0)): v * (1/sqrt((xx+yy)+(zz+ww))); returns the w component 0 * inversesqrt
 __device__ __forceinline__ float normalize_w0(float &x, float &y, float &z)
 {
@@ -1352,7 +1553,11 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
     if constexpr (SVO) {
 #if VK_SVO_BLOCKS
         // one path per wavefront, as in trace_dense
+#if VK_ASM_SVO
+        if (svo_is_regular(svo) && __all(ray_is_regular(ray_hi))) hi = trace_svo_blocks_asm(svo, ray_hi, sx, sy, sz);
+#else
         if (svo_is_regular(svo) && __all(ray_is_regular(ray_hi))) hi = trace_svo_blocks(svo, ray_hi, sx, sy, sz);
+#endif
         else
 #endif
             hi = trace_svo(svo, ray_hi, sx, sy, sz);
