@@ -29,11 +29,20 @@ host: $(LIBDIR)/libvolly_host.so
 oracle: oracle/libvolly_oracle.so
 
 GPU_SRC := $(PKG)/csrc/volly_gpu.hip $(PKG)/csrc/volly_voxelize.hip
-GPU_HDR := $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_refill.h $(PKG)/csrc/volly_requeue.h $(PKG)/csrc/volly_internal.h include/volly_gpu.h tools/check_kernel_contract.py
+GPU_HDR := $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_internal.h include/volly_gpu.h tools/check_kernel_contract.py
+
+# What the library was built from, recorded inside it (volly_gpu_build_info): the SHA-256 of its sources in the order
+# of GPU_HASHED, and the compiler whose output passed the kernel contract.  tests/test_abi.py recomputes the hash from
+# the tree, so a prebuilt .so that no longer matches its sources -- the only way the assembly loops' register
+# contract could go unchecked -- fails the CPU suite here and on the GPU box.
+GPU_HASHED := $(GPU_SRC) $(PKG)/csrc/volly_kernels.h $(PKG)/csrc/volly_internal.h include/volly_gpu.h
+GPU_SRC_SHA = $(shell cat $(GPU_HASHED) | sha256sum | cut -c1-16)
+HIPCC_VER = $(shell $(HIPCC) --version | grep -m1 -i 'HIP version' | tr -d '"' | sed 's/  */ /g')
+BUILDINFO = -DVOLLY_BUILD_SRC_SHA='"$(GPU_SRC_SHA)"' -DVOLLY_BUILD_HIPCC='"$(HIPCC_VER)"'
 
 $(LIBDIR)/libvolly_gpu.so: $(GPU_SRC) $(GPU_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(GPUFLAGS) -o $@ $(GPU_SRC)
+	$(HIPCC) $(GPUFLAGS) $(BUILDINFO) -o $@ $(GPU_SRC)
 	python3 tools/check_kernel_contract.py || { rm -f $@; exit 1; }
 
 $(LIBDIR)/libvolly_host.so: $(HOST_SRC) $(HOST_HDR)
@@ -67,18 +76,16 @@ tools/_bin/magic_floor: tools/magic_floor.hip
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 $(FPFLAGS) -Wno-unused-result -o $@ $<
 
 # alternative builds of the kernels for A/B measurement (profiles/ab_bench.py); never loaded by the product
-# `experimental` also holds the two frame kernels round 1 measured and did not adopt (volly_refill.h,
-# volly_requeue.h; tests/test_gpu_variants.py runs them when this build is present)
 VARDIR := $(LIBDIR)/variants
-VARIANTS ?= experimental:-DVK_EXPERIMENTAL=1 checked:-DVK_FAST_DDA=0 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 waves4:-DVK_WAVE_BLOCK=4 \
+VARIANTS ?= checked:-DVK_FAST_DDA=0 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 waves4:-DVK_WAVE_BLOCK=4 \
             longdiv:-DVK_SHORT_DIV=0 index32:-DVK_INDEX24=0 ckpt4:-DVK_CKPT_STRIDE=4 packc:-DVK_PACK_ASM=0 noasm:-DVK_ASM_QUIET=0 \
-            noasmextra:-DVK_ASM_EXTRA=0 noasmbricks:-DVK_ASM_BRICKS=0 nobfi:-DVK_SIGN_BFI=0 w6:-DVK_PROBE_WAVES=6 w4:-DVK_PROBE_WAVES=4 \
+            noasmextra:-DVK_ASM_EXTRA=0 noasmbricks:-DVK_ASM_BRICKS=0 svocpp:-DVK_ASM_SVO=0 svonodes:-DVK_SVO_BLOCKS=0 nobfi:-DVK_SIGN_BFI=0 w6:-DVK_PROBE_WAVES=6 w4:-DVK_PROBE_WAVES=4 \
             slp:-fslp-vectorize ahead0:-DVK_RUN_AHEAD=0 count:-DVK_COUNT=1
 variants:
 	@mkdir -p $(VARDIR)
 	for v in $(VARIANTS); do \
 	  n=$${v%%:*}; f="$${v#*:}"; \
-	  $(HIPCC) $(GPUFLAGS) $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(GPU_SRC) || exit 1; \
+	  $(HIPCC) $(GPUFLAGS) $(BUILDINFO) $$f -o $(VARDIR)/libvolly_gpu_$$n.so $(GPU_SRC) || exit 1; \
 	  python3 tools/check_kernel_contract.py $$f || exit 1; \
 	done
 

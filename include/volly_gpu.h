@@ -241,7 +241,7 @@ int volly_gpu_read_low_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t c
 int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leaves);
 
 /* Scene facts: 0 sx, 1 sy, 2 sz, 3 is_svo, 4 has_low, 5 low sx, 6 device,
- * 7 device bytes held (MiB), 8 frame kernel (0 tile per wavefront, 1 ray refill, 2 budgeted rounds with parked rays),
+ * 7 device bytes held (MiB), 8 frame kernel (always 0 = one tile per wavefront; the experimental kernels left the library),
  * 9 target grid uses the 16^3 region level, 10 octree nodes, 11 octree leaves,
  * 12 octree depth, 13 a dense target grid is held,
  * 14 the DDA loop the TARGET grid is traversed with: 0 = octree (not a dense traversal), 1 = the assembly
@@ -284,6 +284,12 @@ int volly_gpu_sky_spans_for(const int32_t size_hi[3], const int32_t size_lo[3], 
 void        volly_gpu_free(volly_gpu_scene *scene);
 const char *volly_gpu_last_error(void);
 int         volly_gpu_abi_version(void);
+/* What this binary was built from: "src_sha16=<first 16 hex digits of the SHA-256 of volly_gpu.hip, volly_voxelize.hip,
+ * volly_kernels.h, volly_internal.h, volly_gpu.h, concatenated in that order>; hipcc=<compiler version>; ...".  The
+ * hand-written loops keep state in fixed registers across asm statements, which tools/check_kernel_contract.py verifies
+ * on the compiler's output at build time only; this string lets a prebuilt library be told from one that matches the
+ * tree (tests/test_abi.py does).  No reference counterpart. */
+const char *volly_gpu_build_info(void);
 
 /* The integer mix behind volume_gpu_generate_noise, usable on host and device. */
 #if defined(__HIPCC__)

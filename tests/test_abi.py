@@ -24,7 +24,18 @@ def test_gpu_library_exports_every_declared_symbol(vra):
     for n in names:
         assert hasattr(vra.gpu.lib, n), f"libvolly_gpu.so does not export {n}"
     assert set(names) == set(vra.gpu.EXPORTS)
-    assert vra.gpu.lib.volly_gpu_abi_version() == 2
+    assert vra.gpu.lib.volly_gpu_abi_version() == 3
+
+
+def test_the_prebuilt_gpu_library_matches_the_tree(vra):
+    """The assembly loops keep state in fixed registers across asm statements; tools/check_kernel_contract.py checks
+    that on the compiler's output when `make gpu` builds the library -- and only then.  The library records the hash
+    of the sources it was built from: a .so that is older than the tree (or was built from other sources) fails here,
+    on the CPU and on the GPU box, instead of rendering with unchecked loops."""
+    info = vra.gpu.build_info()
+    assert info.get("src_sha16") == vra.gpu.source_sha16(ROOT), (
+        f"libvolly_gpu.so was built from other sources than this tree's ({info.get('text')}): run `make gpu`")
+    assert info.get("hipcc", "unknown") != "unknown" and "contract" in info["text"]
 
 
 def test_host_library_exports_every_declared_symbol(vra):

@@ -103,6 +103,59 @@ def test_random_scene_camera_frame(vra, ora, case):
     scene.close()
 
 
+SVO_CASES = list(range(int(os.environ.get("VOLLY_RANDOM_SVO_CASES", "24"))))
+
+
+@pytest.mark.parametrize("case", SVO_CASES)
+def test_random_octree(vra, ora, case):
+    """Octree targets only, drawn to reach both traversals: cubic grids whose side is a multiple of 8 -- powers of two and
+    not (res < 2^depth: cells of the tree beyond the grid) -- take the flattened tree (table + occupancy blocks, the
+    assembly loop; scene_info 16), other sides the node chain; sparse to dense fillings, cameras inside, outside, on cell
+    boundaries and axis-parallel (irregular rays: the node chain whatever the tree), beam and naive frames."""
+    rng = np.random.default_rng(5000 + case)
+    res = int([8, 16, 24, 32, 40, 56, 64, 72, 100, 128, 20, 96][case % 12])
+    density = [0.0005, 0.004, 0.05, 0.4][(case // 3) % 4]
+    vox = _random_grid(rng, (res,) * 3, density, blobs=int(rng.integers(0, 5)))
+    f_low = int(rng.choice([2, 4, 8]))
+    low = _low_of(vox, f_low)
+    scene = vra.HostScene.from_dense(vox, low, svo=True)
+    gpu = vra.GpuScene.upload_svo(scene.svo, scene.low)
+    # (an empty tree deeper than three levels has no level-3 node: it takes the node chain)
+    assert gpu.info(16) == (1 if res % 8 == 0 and (gpu.info(11) > 0 or res == 8) else 0)
+    hi, lo = (res,) * 3, (low.shape[2], low.shape[1], low.shape[0])
+    w, h = int(rng.integers(8, 120)), int(rng.integers(8, 90))
+    frames = []
+    for k in range(3):
+        kind = (case + k) % 5
+        if kind == 0:
+            pos = rng.random(3)
+        elif kind == 1:
+            pos = np.round(rng.random(3) * res) / res
+        else:
+            pos = 0.5 + (rng.random(3) - 0.5) * rng.uniform(1.2, 3.0)
+        if kind == 3:
+            d = np.zeros(3)
+            d[int(rng.integers(0, 3))] = rng.choice([-1.0, 1.0])
+            center = pos + d
+        else:
+            center = 0.5 + (rng.random(3) - 0.5) * 0.6
+        if np.allclose(center, pos):
+            center = pos + np.array([0.3, 0.2, 0.1])
+        up = (0, 0, -1) if abs((center - pos)[2]) < 0.9 * np.linalg.norm(center - pos) else (0, 1, 0)
+        view = vra.look_at(pos.astype(np.float32), center.astype(np.float32), up)
+        frames.append(vra.frame_from_camera(view, pos.astype(np.float32), hi, lo, w, h, naive=bool(rng.integers(0, 2))))
+    got = gpu.render(frames, planes=ALL)
+    five = gpu.render(frames)
+    hits = 0
+    for i, f in enumerate(frames):
+        want = ora.render_frame(f, low=scene.low, svo=scene.svo, planes=ALL)
+        hits += int((want["hit_index"] != MISS).sum())
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"octree case {case} frame {i} res {res} flags {f.flags}")
+        assert_planes_equal({k: v[i] for k, v in five.items()}, want, f"octree case {case} frame {i} res {res} flags {f.flags}, five planes")
+    gpu.close()
+    scene.close()
+
+
 def test_the_random_cases_reach_hits_and_misses(vra, ora):
     """Guard against a vacuous suite: over a few of the cases above there must be hits, misses
     and rays that take steps in both grids."""

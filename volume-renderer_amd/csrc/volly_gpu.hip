@@ -1,17 +1,6 @@
 // volly_gpu.hip -- C-ABI of the MI355X traversal path (include/volly_gpu.h).
 // Built for gfx950 only, with -ffp-contract=off (see volly_kernels.h).
 #include "volly_internal.h"
-// VK_EXPERIMENTAL=1 (the `experimental` build of `make variants`, never the shipped library) adds the
-// two frame kernels round 1 measured and did not adopt: ray refill (VOLLY_REFILL=1) and budgeted
-// rounds with parked rays (VOLLY_REQUEUE=1); tests/test_gpu_variants.py keeps them bit-exact.
-#ifndef VK_EXPERIMENTAL
-#define VK_EXPERIMENTAL 0
-#endif
-#if VK_EXPERIMENTAL
-#include "volly_refill.h"
-#include "volly_requeue.h"
-#endif
-
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -168,7 +157,6 @@ void destroy(volly_gpu_scene *s)
     if (s->d_ckpt) (void)hipFree(s->d_ckpt);
     if (s->d_spans) (void)hipFree(s->d_spans);
     if (s->d_planes) (void)hipFree(s->d_planes);
-    if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->s_render) (void)hipStreamDestroy(s->s_render);
     if (s->s_copy) (void)hipStreamDestroy(s->s_copy);
     delete s;
@@ -195,31 +183,6 @@ int new_scene(int device, volly_gpu_scene **out)
 static bool host_grid_is_regular(const vk::DenseDev &g)
 {
     return ((g.sx | g.sy | g.sz) & 15) == 0 && g.sx <= 1024 && g.sy <= 1024 && g.sz <= 1024;
-}
-
-// The ray-refill frame kernel (volly_refill.h) is an experiment kept for measurement: on the
-// noise volume it was built for it needs 25 % fewer VALU instructions than the tile kernel but
-// issues 8x the L2 requests (lanes no longer share brick lines) and runs its per-ray set-up
-// at 25 % lane packing: 5.3 ms against 4.6 ms.  Off unless VOLLY_REFILL=1.
-void choose_frame_kernel(volly_gpu_scene *s)
-{
-#if !VK_EXPERIMENTAL
-    s->refill = s->requeue = false;                      // the shipped library has one dense and one octree frame kernel
-    return;
-#endif
-    bool ok = !s->is_svo && host_grid_is_regular(s->target) && (!s->has_low || host_grid_is_regular(s->low));
-    bool want = false;
-    if (const char *e = std::getenv("VOLLY_REFILL")) want = ok && std::atoi(e) != 0;
-    s->refill = want;
-    // Budgeted rounds with a queue of parked rays (volly_requeue.h), meant for scenes whose ray
-    // lengths scatter.  Measured on the 1024^3 noise volume it gains 5 % at best (3.62 against
-    // 3.81 ms, budget 160): there a step costs twice the arithmetic because nearly every step
-    // enters a new brick, the tile kernel's lanes are busy half of the time, not a fifth, and the
-    // later rounds lose the coherence of neighbouring rays.  Kept as an opt-in: VOLLY_REQUEUE=1.
-    const bool eligible = !s->is_svo && host_grid_is_regular(s->target);
-    bool rq = false;
-    if (const char *e = std::getenv("VOLLY_REQUEUE")) rq = eligible && std::atoi(e) != 0;
-    s->requeue = rq && !s->refill;
 }
 
 int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res,
@@ -548,9 +511,6 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
     } else if (n > vk::kInlineFrames || need > kNoAllocCkptFloats || need_spans > kNoAllocSpans)
         return fail(VOLLY_E_ARG, "render: batch does not fit the static scratch");
     int cull = outs->pt_end ? 0 : s->sky_cull;               // ptEnd of a miss is the reference's arithmetic: no shortcut
-#if VK_EXPERIMENTAL
-    if ((s->requeue || s->refill) && !any_raytrace && !no_alloc) cull = 0;   // those kernels have no sky test: every checkpoint is read
-#endif
     // The descriptors travel as kernel arguments, kInlineFrames per pre-pass launch: no host-to-device copy (from
     // pageable memory it would block the host and leave the queue empty between calls).  The pre-pass leaves
     // them in the scratch where the frame kernel reads them, and turns each frame's sky rectangle and hull
@@ -588,45 +548,6 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         HIP_TRY(hipEventRecord(e0, stream));
     }
     dim3 grid((unsigned)((tw + block_w - 1) / block_w), (unsigned)((th + block_h - 1) / block_h), (unsigned)n);
-#if VK_EXPERIMENTAL
-    if (s->requeue && !any_raytrace && !no_alloc) {
-        const size_t n_px = (size_t)n * tw * th;
-        if (n_px >= (1ull << 32)) return fail(VOLLY_E_ARG, "render: more than 2^32 pixels per launch");
-        if (n_px > s->queue_rays) {
-            if (s->d_queue) { HIP_TRY(hipFree(s->d_queue)); s->d_queue = nullptr; s->queue_rays = 0; }
-            HIP_TRY(hipMalloc(&s->d_queue, 64 + 2 * n_px * sizeof(vk::RayState)));
-            s->queue_rays = n_px;
-        }
-        uint32_t *counts = (uint32_t *)s->d_queue;                          // [0], [1]: the two queues' fill
-        vk::RayState *items = (vk::RayState *)((char *)s->d_queue + 64);
-        vk::QueueDev q[2] = {{items, counts, (uint32_t)n_px}, {items + s->queue_rays, counts + 1, (uint32_t)n_px}};
-        uint32_t budget = (uint32_t)std::min(std::max((s->target.sx + s->target.sy + s->target.sz) / 12, 32), 1024);
-        if (const char *e = std::getenv("VOLLY_REQUEUE_BUDGET")) budget = (uint32_t)std::max(std::atoi(e), 1);
-        HIP_TRY(hipMemsetAsync(counts, 0, 8, stream));
-        dim3 tiles((unsigned)((tw + vk::kTile - 1) / vk::kTile), (unsigned)((th + vk::kTile - 1) / vk::kTile), (unsigned)n);
-        hipLaunchKernelGGL(vk::render_frames_budget, tiles, dim3(64), 0, stream, s->target, s->low, d_frames, d_ckpt, o, q[0], budget);
-        HIP_TRY(hipGetLastError());
-        // every round continues the rays the previous one parked; the span doubles, and the last
-        // round runs to the iteration cap, where every ray ends
-        const unsigned cont_blocks = (unsigned)std::min<size_t>((n_px + 63) / 64, 8192);
-        int cur = 0;
-        for (uint32_t iter0 = budget, span = 2 * budget; iter0 < s->target.cap; iter0 += span, span *= 2) {
-            const bool last = (uint64_t)iter0 + span >= s->target.cap;
-            const uint32_t iter_end = last ? 0xFFFFFFFFu : iter0 + span;
-            HIP_TRY(hipMemsetAsync(q[cur ^ 1].count, 0, 4, stream));
-            hipLaunchKernelGGL(vk::continue_rays, dim3(cont_blocks), dim3(64), 0, stream, s->target, d_frames, (uint32_t)(tw * th), q[cur],
-                               q[cur ^ 1], o, iter0, iter_end);
-            HIP_TRY(hipGetLastError());
-            cur ^= 1;
-            if (last) break;
-        }
-    } else if (s->refill && !any_raytrace && !no_alloc) {
-        const unsigned tiles = (unsigned)((tw + vk::kTile - 1) / vk::kTile) * (unsigned)((th + vk::kTile - 1) / vk::kTile);
-        const unsigned waves = (tiles + vk::kRaysPerWave / 64 - 1) / (vk::kRaysPerWave / 64);
-        hipLaunchKernelGGL(vk::render_frames_refill, dim3((waves + 3) / 4, (unsigned)n), dim3(vk::kThreads), 0, stream, s->target,
-                           s->low, d_frames, d_ckpt, o);
-    } else
-#endif
     if (s->is_svo && all_naive)
         hipLaunchKernelGGL((vk::render_frames<true, false, vk::kTileNaive>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
                            d_spans, d_ckpt, o);
@@ -655,7 +576,19 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
 
 extern "C" {
 
-int volly_gpu_abi_version(void) { return 2; }
+int volly_gpu_abi_version(void) { return 3; }
+
+#ifndef VOLLY_BUILD_SRC_SHA
+#define VOLLY_BUILD_SRC_SHA "unknown"
+#endif
+#ifndef VOLLY_BUILD_HIPCC
+#define VOLLY_BUILD_HIPCC "unknown"
+#endif
+const char *volly_gpu_build_info(void)
+{
+    return "src_sha16=" VOLLY_BUILD_SRC_SHA "; hipcc=" VOLLY_BUILD_HIPCC
+           "; kernel contract (m0, v44-v63, at most 64 VGPRs, no spills) checked on this compiler's assembly by tools/check_kernel_contract.py at build";
+}
 
 const char *volly_gpu_last_error(void) { return g_err.c_str(); }
 
@@ -676,7 +609,6 @@ int volume_gpu_upload(int device, const volly_dense_desc *target, const volly_de
         s->has_low = true;
     }
     if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
-    choose_frame_kernel(s);
     *out = s;
     return VOLLY_OK;
 }
@@ -770,7 +702,6 @@ int volume_gpu_generate_noise(int device, int32_t res, uint32_t seed, uint32_t t
     if (!rc) rc = make_dense(s, lr, lr, lr, nullptr, vox_lo, &s->low);
     if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
     s->has_low = true;
-    choose_frame_kernel(s);
     *out = s;
     return VOLLY_OK;
 }
@@ -1031,7 +962,7 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 5: return s->has_low ? s->low.sx : 0;
     case 6: return s->device;
     case 7: return (int64_t)(s->bytes >> 20);
-    case 8: return s->refill ? 1 : (s->requeue ? 2 : 0);
+    case 8: return 0;
     case 9: return s->is_svo ? 0 : s->target.use_regions;
     case 10: return s->svo.nodes ? (int64_t)s->svo.n_nodes : 0;
     case 11: return s->svo.nodes ? (int64_t)s->n_leaves : 0;

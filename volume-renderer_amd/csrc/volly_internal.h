@@ -47,10 +47,6 @@ struct DeviceGuard {
 struct volly_gpu_scene {
     int device = 0;
     bool is_svo = false, has_low = false;
-    bool refill = false;            // use the ray-refill frame kernel (experiment, VOLLY_REFILL=1)
-    bool requeue = false;           // rays of very uneven length: budgeted rounds with a queue of parked rays (volly_requeue.h)
-    void *d_queue = nullptr;        // two queues of parked rays + their counters
-    size_t queue_rays = 0;
     vk::DenseDev target{}, low{};
     vk::SvoDev svo{};
     uint32_t n_leaves = 0;
@@ -89,7 +85,6 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
 // level-3 nodes are the index range [l3_first, l3_first + l3_count) (l3_first < 0: unknown), its occupancy blocks
 int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res,
                int64_t l3_first, int64_t l3_count);
-void choose_frame_kernel(volly_gpu_scene *s);
 
 } // namespace vimpl
 

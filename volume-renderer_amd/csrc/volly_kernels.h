@@ -52,9 +52,9 @@
 //                     straight from registers: no LDS, no barrier, 1/N of the workgroup dispatches
 // Designs that were measured and rejected in round 1 -- sampling the 8-byte voxels at every step,
 // a 32x2 wavefront tile, output rows staged through LDS, an XCD-contiguous block order, several
-// tiles per wavefront, the top of the octree in LDS, the ray-refill and parked-ray frame kernels
-// -- are no longer in this file: DESIGN.md section 5 has their numbers, profiles/r01_ab/ the logs,
-// the history (commit cfca876) the code.  Round 2's brick layout with a 2x2x2 block of bricks per
+// tiles per wavefront, the top of the octree in LDS -- are no longer in this file: DESIGN.md has their
+// numbers, profiles/r01_ab/ the logs, the history (commit cfca876) the code.  The ray-refill and parked-ray
+// frame kernels (volly_refill.h, volly_requeue.h: measured, not adopted) left the tree in round 3: commit 732586d holds them.  Round 2's brick layout with a 2x2x2 block of bricks per
 // 64-byte line (-31 % L2 reads, +2.4 % time on the noise volume; profiles/r02_ab/ab_brick_blocks_c3.log)
 // is in commit e1ece63; round 1's assembly loops, which handed hits and grid exits to compiled code, are
 // in commit 7641e49 (profiles/r02_ab/r02_ab_whole_c*.log).
@@ -102,7 +102,6 @@ static_assert(VK_WAVE_BLOCK >= 1, "wavefronts per workgroup");
 
 namespace vk {
 
-constexpr int kTile = 8;            // tile edge of the experimental kernels (volly_refill.h, volly_requeue.h)
 constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pixels of a row (at most kCkpt - 1 adds per lane)
 // The wavefront's tile in the frame kernel is TW x 64/TW pixels (template parameter of render_frames):
 // 8 x 8 for frames with a beam pass -- the most compact ray bundle, fewest attention steps -- and 32 x 2 for

@@ -52,11 +52,36 @@ _sig = {
     "volly_gpu_free": (None, [_vp]),
     "volly_gpu_last_error": (C.c_char_p, []),
     "volly_gpu_abi_version": (C.c_int, []),
+    "volly_gpu_build_info": (C.c_char_p, []),
 }
 for _name, (_res, _args) in _sig.items():
     _fn = getattr(lib, _name)
     _fn.restype, _fn.argtypes = _res, _args
 EXPORTS = tuple(_sig)
+
+
+GPU_SOURCES = ("volume-renderer_amd/csrc/volly_gpu.hip", "volume-renderer_amd/csrc/volly_voxelize.hip", "volume-renderer_amd/csrc/volly_kernels.h",
+               "volume-renderer_amd/csrc/volly_internal.h", "include/volly_gpu.h")      # Makefile: GPU_HASHED, same order
+
+
+def build_info():
+    """volly_gpu_build_info as a dict: src_sha16, hipcc, ..."""
+    text = (lib.volly_gpu_build_info() or b"").decode()
+    out = {"text": text}
+    for part in text.split(";"):
+        if "=" in part:
+            k, v = part.strip().split("=", 1)
+            out[k] = v
+    return out
+
+
+def source_sha16(root):
+    """The hash `make gpu` records in the library, recomputed from the tree under `root`."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in GPU_SOURCES:
+        h.update(open(os.path.join(root, rel), "rb").read())
+    return h.hexdigest()[:16]
 
 
 class VollyError(RuntimeError):
