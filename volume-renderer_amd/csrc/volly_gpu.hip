@@ -526,7 +526,7 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
             sky_rect(s, frames[base + i], cull != 0, batch.cull[i], batch.hull[i]);
             if (cull < 2) for (int e = 0; e < vk::kHullEdges; ++e) { batch.hull[i][e][0] = 0.f; batch.hull[i][e][1] = 0.f; batch.hull[i][e][2] = -1.f; }
         }
-        const dim3 pre_grid((unsigned)((th + 63) / 64), (unsigned)nb, 6);
+        const dim3 pre_grid((unsigned)((th + 63) / 64), (unsigned)nb, all_naive ? 3 : 6);      // naive frames need the target sums only
         hipLaunchKernelGGL(vk::direction_checkpoints_inline, pre_grid, dim3(64), 0, stream, batch, nb, d_frames + base, d_spans, d_ckpt, base, block_h);
     }
     HIP_TRY(hipGetLastError());

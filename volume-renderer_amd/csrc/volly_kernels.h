@@ -108,7 +108,10 @@ constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pi
 // launches of naive frames only, which are bound by the output path: 128-byte instead of 32-byte row
 // segments per store (0.64 -> 0.52 ms on the headline frames in naive mode, profiles/r02_ab/ab_tile_shapes.log;
 // in beam mode 16 x 4 is neutral and 32 x 2 is 5-12 % slower).
-constexpr int kTileBeam = 8, kTileNaive = 32;
+#ifndef VK_TILE_NAIVE
+#define VK_TILE_NAIVE 32
+#endif
+constexpr int kTileBeam = 8, kTileNaive = VK_TILE_NAIVE;
 #ifdef VK_PROBE_WAVES            // measurement only: cap the resident wavefronts per SIMD through the register allocation
 #define VK_FRAME_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(VK_PROBE_WAVES, VK_PROBE_WAVES)))
 #else
@@ -1452,6 +1455,8 @@ struct PixelOut {
 // the six direction sums of a pixel's checkpoint (target xyz, low xyz)
 struct Ckpt { float v[6]; };
 
+// NAIVE_ONLY (launches of naive frames only): the low-grid sums are neither stored by the pre-pass nor read
+template <bool NAIVE_ONLY>
 __device__ __forceinline__ Ckpt load_checkpoint(const float *__restrict__ ckpt, const volly_frame_desc &fd, int f, int xrel, int yrel)
 {
     // checkpoint scratch of one launch stays below 2^31 floats (render_chunk): 32-bit indices
@@ -1460,12 +1465,13 @@ __device__ __forceinline__ Ckpt load_checkpoint(const float *__restrict__ ckpt, 
     const float *c = ckpt + (((uint32_t)f * groups + (uint32_t)xrel / (uint32_t)kCkpt) * 6u * cs + (uint32_t)yrel);
     Ckpt k;
     #pragma unroll
-    for (int i = 0; i < 6; ++i) k.v[i] = c[(uint32_t)i * cs];
+    for (int i = 0; i < (NAIVE_ONLY ? 3 : 6); ++i) k.v[i] = c[(uint32_t)i * cs];
+    if (NAIVE_ONLY) k.v[3] = k.v[4] = k.v[5] = 0.0f;
     return k;
 }
 
 // main.cpp:256-272 for one pixel, from its checkpoint
-template <bool SVO, bool RAYTRACE>
+template <bool SVO, bool RAYTRACE, bool NAIVE_ONLY>
 __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const SvoDev &svo, const DenseDev &low, const volly_frame_desc &fd,
                                                  const Ckpt &k, int xrel)
 {
@@ -1480,16 +1486,36 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
         const float ah = fd.xdiff_hi[0], bh = fd.xdiff_hi[1], ch = fd.xdiff_hi[2];
         const float al = fd.xdiff_lo[0], bl = fd.xdiff_lo[1], cl = fd.xdiff_lo[2];
         (void)xrel;
-#define VK_EXTRA_ROUND(MASK)                                                                     \
+#define VK_EXTRA_ROUND_HI(MASK)                                                                  \
             "s_and_b32 exec_lo, %[save0], " MASK "\n\t"                                          \
             "s_and_b32 exec_hi, %[save1], " MASK "\n\t"                                          \
             "v_add_f32 %[hx], %[hx], %[ah]\n\t"                                                  \
             "v_add_f32 %[hy], %[hy], %[bh]\n\t"                                                  \
-            "v_add_f32 %[hz], %[hz], %[ch]\n\t"                                                  \
+            "v_add_f32 %[hz], %[hz], %[ch]\n\t"
+#define VK_EXTRA_ROUND(MASK)                                                                     \
+            VK_EXTRA_ROUND_HI(MASK)                                                              \
             "v_add_f32 %[lx], %[lx], %[al]\n\t"                                                  \
             "v_add_f32 %[ly], %[ly], %[bl]\n\t"                                                  \
             "v_add_f32 %[lz], %[lz], %[cl]\n\t"
         uint32_t save0, save1;
+        if constexpr (NAIVE_ONLY) {                       // the low-grid sums are not needed: three adds per round
+            asm volatile(
+                "s_mov_b32 %[save0], exec_lo\n\t"
+                "s_mov_b32 %[save1], exec_hi\n\t"
+                VK_EXTRA_ROUND_HI("0xfefefefe")
+                VK_EXTRA_ROUND_HI("0xfcfcfcfc")
+                VK_EXTRA_ROUND_HI("0xf8f8f8f8")
+                VK_EXTRA_ROUND_HI("0xf0f0f0f0")
+                VK_EXTRA_ROUND_HI("0xe0e0e0e0")
+                VK_EXTRA_ROUND_HI("0xc0c0c0c0")
+                VK_EXTRA_ROUND_HI("0x80808080")
+                "s_mov_b32 exec_lo, %[save0]\n\t"
+                "s_mov_b32 exec_hi, %[save1]"
+                : [hx] "+v"(hx), [hy] "+v"(hy), [hz] "+v"(hz), [save0] "=&s"(save0), [save1] "=&s"(save1)
+                : [ah] "s"(ah), [bh] "s"(bh), [ch] "s"(ch)
+                : "scc");
+            (void)al; (void)bl; (void)cl;
+        } else
         asm volatile(
             "s_mov_b32 %[save0], exec_lo\n\t"
             "s_mov_b32 %[save1], exec_hi\n\t"
@@ -1507,6 +1533,7 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
             : [ah] "s"(ah), [bh] "s"(bh), [ch] "s"(ch), [al] "s"(al), [bl] "s"(bl), [cl] "s"(cl)
             : "scc");
 #undef VK_EXTRA_ROUND
+#undef VK_EXTRA_ROUND_HI
     }
 #else
     const int extra = xrel % kCkpt;
@@ -1538,7 +1565,7 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
     (void)hw;
 
     float sx, sy, sz;                                     // start of the target-grid pass
-    if (fd.flags & VOLLY_FRAME_NAIVE) {                   // main.cpp:261
+    if (NAIVE_ONLY || (fd.flags & VOLLY_FRAME_NAIVE)) {   // main.cpp:261
         sx = fd.origin_hi[0]; sy = fd.origin_hi[1]; sz = fd.origin_hi[2];
     } else {                                              // raycast_beamOpt, main.cpp:163-166
         normalize_w0(lx, ly, lz);
@@ -1601,8 +1628,9 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
         const bool sky = (tx + TW - 1 < span.x) | (tx > span.y);
         PixelOut o;
         if (!sky) {
-            const Ckpt k = load_checkpoint(ckpt, fd, f, xrel, yrel);
-            o = render_pixel<SVO, RAYTRACE>(target, svo, low, fd, k, xrel);
+            constexpr bool kNaiveOnly = TW == kTileNaive && !RAYTRACE;     // this instantiation serves launches of naive frames only
+            const Ckpt k = load_checkpoint<kNaiveOnly>(ckpt, fd, f, xrel, yrel);
+            o = render_pixel<SVO, RAYTRACE, kNaiveOnly>(target, svo, low, fd, k, xrel);
         }
         const size_t p = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)yrel * (size_t)fd.tile_w + (size_t)xrel;
         if (out.rgba8) out.rgba8[p] = o.rgba;
