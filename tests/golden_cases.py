@@ -45,6 +45,9 @@ for tgt in ("dense", "svo"):
 # BASELINE config 2: dragon.off at 512^3 octree, 1920x1080 (CRCs only)
 CASES["dragon512_svo_1080p"] = dict(scene_key="dragon512", kind="mesh", mesh="dragon.off", res=512, target="svo",
                                     w=1920, h=1080, cams=("orbit", [(5, 32, 1.0)]), naive=False, store=False, dense=False)
+# BASELINE config 4: galleon.ply at 2048^3 octree, the whole 7680x4320 frame (33 M rays; CRCs only; hit_index mod 2^32)
+CASES["galleon2048_svo_8k"] = dict(scene_key="galleon2048", kind="mesh", mesh="galleon.ply", res=2048, target="svo",
+                                   w=7680, h=4320, cams=("orbit", [(300, 4096, 1.0)]), naive=False, store=False, dense=False, threads=16)
 
 _scene_cache = {}
 
@@ -111,7 +114,7 @@ def render_case(vra, ora, case, backend):
     """dict plane -> (n_frames, h, w) array, and the scene digest."""
     frames, low, target, svo, scene = case_inputs(vra, case)
     if backend == "oracle":
-        per = [ora.render_frame(f, low=low, target=target, svo=svo) for f in frames]
+        per = [ora.render_frame(f, low=low, target=target, svo=svo, threads=case.get("threads", 8)) for f in frames]
         planes = {p: np.stack([r[p] for r in per]) for p in per[0]}
     else:
         gpu = vra.GpuScene.upload_dense(target, low) if target is not None else vra.GpuScene.upload_svo(svo, low)

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ASSETS, MISS, assert_planes_equal
+from conftest import ROOT, ASSETS, MISS, assert_planes_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -310,6 +310,40 @@ def test_north_star_dragon1024_octree_full_4k_frame(vra, ora):
     scene.close()
 
 
+def test_camera_regimes_dragon1024_full_4k_frames(vra, ora):
+    """The regimes bench.py's headline orbit avoids (bench.py --camera), each as one full 3840x2160 frame of the
+    north-star scene against the oracle, all five planes bit for bit:
+      startup  the reference's own start-up state, camPos = 0 (a corner of the grid, main.h:96) and camDir from the
+               mouse at (0, 0) (main.cpp:393-397): every ray starts at the grid, nothing is sky, the cull is off;
+      inside   the orbit at radius 0.25: the camera inside the grid (= the model's bounding box);
+      fill     the orbit at radius 0.5: the model fills the frame (hit fraction >= 0.5).
+    Beam mode (the live path) for all three, naive mode (pure octree traversal) for inside and fill."""
+    import bench
+    scene = vra.HostScene.from_mesh(os.path.join(ASSETS, "dragon.off"), 1024, dense=False, svo=True)
+    hi, lo = (1024,) * 3, (256,) * 3
+    gpu = vra.GpuScene.upload_svo(scene.svo, scene.low)
+    assert gpu.info(16) == 1
+    W, H = 3840, 2160
+    view0 = vra.look_at((0, 0, 0), vra.host.cam_dir_from_mouse(0, 0), (0, 0, -1))
+    cases = [("startup", False, vra.frame_from_camera(view0, (0.0, 0.0, 0.0), hi, lo, W, H)),
+             ("startup", True, vra.frame_from_camera(view0, (0.0, 0.0, 0.0), hi, lo, W, H, naive=True))]
+    for cam, view in (("inside", 1300), ("fill", 2048)):
+        for naive in (False, True):
+            cases.append((cam, naive, vra.orbit_frames((view,), 4096, hi, lo, W, H, radius=bench.CAMERA_RADIUS[cam], naive=naive)[0]))
+    for cam, naive, f in cases:
+        want = ora.render_frame(f, low=scene.low, svo=scene.svo, threads=16)
+        got = gpu.render(f)
+        assert_planes_equal({k: v[0] for k, v in got.items()}, want, f"dragon1024 4K camera={cam} naive={naive}")
+        hit = float((want["hit_index"] != MISS).mean())
+        if cam == "startup":
+            assert gpu.sky_rect(f) == (0, W - 1, 0, H - 1)                      # no cull from inside / at the grid
+            assert int(want["steps_hi" if naive else "steps_lo"].min()) >= 1      # every ray samples: none is sky
+        else:
+            assert hit >= 0.5, (cam, hit)
+    gpu.close()
+    scene.close()
+
+
 def test_config5_dragon1024_from_the_scene_cache(vra, ora, tmp_path):
     """BASELINE config 5's dragon half, and the on-disk scene cache on the GPU path (the
     reference re-voxelizes every model at every start, main.cpp:369-387): dragon.off is voxelized
@@ -414,23 +448,35 @@ def test_config5_stratocaster1024_full_frame_from_a_device_built_scene(vra, ora)
         s_.close()
 
 
-def test_config4_galleon2048_row_bands_of_an_8k_frame(vra, ora):
-    """BASELINE config 4: galleon.ply at 2048^3 (octree only; hit_index is taken mod 2^32 there),
-    one 7680x4320 frame split into row bands.  Two bands of 64 rows, rendered as sub-rectangles
-    the way one GPU of eight would, equal the oracle's rows of the full frame."""
+def test_config4_galleon2048_full_8k_frame_and_its_row_bands(vra, ora):
+    """BASELINE config 4: galleon.ply at 2048^3 (octree only; hit_index is taken mod 2^32 there), the WHOLE
+    7680x4320 frame -- 33 M rays, all five planes bit for bit against the oracle (16 threads), with the sky
+    cull active (pt_end not requested: at this size the serial direction sums drift by pixels, which the cull's
+    margin must cover, sky_drift_margin in volly_gpu.hip) -- and its plane CRCs against tests/golden/golden.json
+    (the assembled-frame CRC).  Then row bands rendered as sub-rectangles, the way one GPU of eight
+    would, against the same oracle rows: 64-row bands at the model's silhouette and a 540-row eighth."""
+    import json
+    from golden_cases import CASES, crc
+    case = CASES["galleon2048_svo_8k"]
     path = os.path.join(ASSETS, "galleon.ply")
     scene = vra.HostScene.from_mesh(path, 2048, dense=False, svo=True)
     mesh = vra.HostMesh(path, 2)
     gpu = vra.GpuScene.voxelize(mesh.desc, 2048, dense=False, svo=True)
-    full = vra.orbit_frames((300,), 4096, (2048,) * 3, (512,) * 3, 7680, 4320, radius=1.0)[0]
-    hits = 0
-    for y0 in (1500, 2160):
-        band = full.band(y0, 64)
-        got = gpu.render(band)
-        want = ora.render_frame(band, low=scene.low, svo=scene.svo, threads=16)
-        hits += int((want["hit_index"] != MISS).sum())
-        assert_planes_equal({k: v[0] for k, v in got.items()}, want, f"galleon2048 rows {y0}..{y0 + 63}")
-    assert hits > 10000
+    assert gpu.info(16) == 1                              # the flattened tree: 256^3-entry table + blocks
+    full = vra.orbit_frames((case["cams"][1][0][0],), 4096, (2048,) * 3, (512,) * 3, 7680, 4320, radius=1.0)[0]
+    want = ora.render_frame(full, low=scene.low, svo=scene.svo, threads=16)
+    got = gpu.render(full)
+    assert_planes_equal({k: v[0] for k, v in got.items()}, want, "galleon2048 full 8K frame")
+    assert (want["hit_index"] != MISS).sum() > 1_000_000
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["cases"]["galleon2048_svo_8k"]
+    for p, a in got.items():
+        assert crc(a) == meta["crc"][p], f"galleon2048 8K: CRC of plane {p} differs from the golden file"
+    rect = gpu.sky_rect(full)
+    assert rect[0] > 0 or rect[1] < 7679 or rect[2] > 0 or rect[3] < 4319      # the cull is active on this frame
+    for y0, rows in ((rect[2], 64), (max(rect[3] - 63, 0), 64), (1500, 64), (4 * 540, 540)):
+        band = full.band(y0, rows)
+        part = gpu.render(band)
+        assert_planes_equal({k: v[0] for k, v in part.items()}, {k: v[y0:y0 + rows] for k, v in want.items()}, f"galleon2048 rows {y0}..{y0 + rows - 1}")
     for s_ in (gpu, mesh, scene):
         s_.close()
 
