@@ -241,7 +241,7 @@ int volly_gpu_read_low_voxels(volly_gpu_scene *scene, uint64_t first, uint64_t c
 int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leaves);
 
 /* Scene facts: 0 sx, 1 sy, 2 sz, 3 is_svo, 4 has_low, 5 low sx, 6 device,
- * 7 device bytes held (MiB), 8 frame kernel (always 0 = one tile per wavefront; the experimental kernels left the library),
+ * 7 device bytes held (MiB), 8 frame kernel (0 = one tile per wavefront, 3 = blocks of four tiles whose rays are packed into full wavefronts between rounds: dense targets without the region level),
  * 9 target grid uses the 16^3 region level, 10 octree nodes, 11 octree leaves,
  * 12 octree depth, 13 a dense target grid is held,
  * 14 the DDA loop the TARGET grid is traversed with: 0 = octree (not a dense traversal), 1 = the assembly

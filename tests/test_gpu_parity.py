@@ -191,7 +191,7 @@ def test_noise_scene_matches_host_hash(vra, ora):
     render of the generated scene equals the oracle on a host rebuild of it."""
     res, seed, thr = 64, 3, 1 << 25
     gpu = vra.GpuScene.noise(res, seed, thr)
-    assert gpu.info(8) == 0 and gpu.info(9) == 0      # every region holds voxels: the region level is switched off
+    assert gpu.info(8) == 3 and gpu.info(9) == 0      # every region holds voxels: no region level, frames through render_frames_packed
     dev = gpu.read_voxels(0, res ** 3).reshape(res, res, res, 8)
     z, y, x = np.meshgrid(np.arange(res, dtype=np.uint32), np.arange(res, dtype=np.uint32),
                           np.arange(res, dtype=np.uint32), indexing="ij")

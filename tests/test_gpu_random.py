@@ -156,6 +156,57 @@ def test_random_octree(vra, ora, case):
     scene.close()
 
 
+PACKED_CASES = list(range(int(os.environ.get("VOLLY_RANDOM_PACKED_CASES", "20"))))
+
+
+@pytest.mark.parametrize("case", PACKED_CASES)
+def test_random_dense_packed_kernel(vra, ora, case, monkeypatch):
+    """vk::render_frames_packed (dense targets without the region level: blocks of four tiles, the rays still under way
+    packed into full wavefronts between rounds) forced onto random regular grids of every filling, with round lengths
+    from 1 iteration (a compaction after every step) to more than any ray takes (none at all): beam and naive frames,
+    several per call, odd sizes and sub-rectangles (blocks that hang over the edge), cameras inside and outside, all six
+    planes bit for bit against the oracle."""
+    rng = np.random.default_rng(9000 + case)
+    budget = [1, 2, 5, 16, 32, 100000][case % 6]
+    monkeypatch.setenv("VOLLY_PACKED", "1")
+    monkeypatch.setenv("VOLLY_PACK_BUDGET", str(budget))
+    shape = tuple(int(16 * rng.integers(1, 5)) for _ in range(3))
+    density = [0.0, 0.001, 0.01, 0.1][(case // 2) % 4]
+    vox = _random_grid(rng, shape, density, blobs=int(rng.integers(0, 3)))
+    low = _low_of(vox, int(rng.choice([2, 4, 8])))
+    scene = vra.HostScene.from_dense(vox, low, svo=False)
+    gpu = vra.GpuScene.upload_dense(scene.target, scene.low)
+    assert gpu.info(8) == 3
+    hi, lo = (shape[2], shape[1], shape[0]), (low.shape[2], low.shape[1], low.shape[0])
+    w, h = int(rng.integers(1, 150)), int(rng.integers(1, 70))
+    frames = []
+    for k in range(int(rng.integers(1, 4))):
+        kind = (case + k) % 4
+        pos = rng.random(3) if kind == 0 else 0.5 + (rng.random(3) - 0.5) * rng.uniform(1.2, 3.0)
+        if kind == 3:                                   # axis-parallel view: irregular rays take the checked loop inside the kernel
+            d = np.zeros(3)
+            d[int(rng.integers(0, 3))] = rng.choice([-1.0, 1.0])
+            center = pos + d
+        else:
+            center = 0.5 + (rng.random(3) - 0.5) * 0.5
+        up = (0, 0, -1) if abs((center - pos)[2]) < 0.9 * np.linalg.norm(center - pos) else (0, 1, 0)
+        view = vra.look_at(pos.astype(np.float32), center.astype(np.float32), up)
+        frames.append(vra.frame_from_camera(view, pos.astype(np.float32), hi, lo, w, h, naive=bool(case % 2)))
+    if case % 3 == 0 and w > 3 and h > 3:
+        x0, y0 = int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))
+        tw, th = int(rng.integers(1, w - x0 + 1)), int(rng.integers(1, h - y0 + 1))
+        for f in frames:
+            f.x0, f.y0, f.tile_w, f.tile_h = x0, y0, tw, th
+    got = gpu.render(frames, planes=ALL)
+    five = gpu.render(frames)
+    for i, f in enumerate(frames):
+        want = ora.render_frame(f, low=scene.low, target=scene.target, planes=ALL)
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"packed case {case} frame {i} shape {shape} budget {budget}")
+        assert_planes_equal({k: v[i] for k, v in five.items()}, want, f"packed case {case} frame {i} shape {shape} budget {budget}, five planes")
+    gpu.close()
+    scene.close()
+
+
 def test_the_random_cases_reach_hits_and_misses(vra, ora):
     """Guard against a vacuous suite: over a few of the cases above there must be hits, misses
     and rays that take steps in both grids."""

@@ -5,7 +5,8 @@ assembly the compiler actually produced (hipcc -S --cuda-device-only, same flags
   1. m0 belongs to the DDA loops: they keep their iteration number there across separate `asm`
      statements and the compiler is not told, so no other instruction of the translation unit may
      touch m0 (indexed registers, LDS-direct, messages, spills through m0 would corrupt the step
-     counts and the iteration cap);
+     counts and the iteration cap): every instruction that names m0 must lie between ASMSTART / ASMEND and be one
+     of the loops' own forms;
   2. occupancy: the live frame kernels -- render_frames<true,false,TW> (octree) and <false,false,TW>
      (dense), TW = 8 and 32 -- stay at <= 64 vector and <= 96 scalar registers, i.e. 8 wavefronts per SIMD, and
      spill nothing.  The loops' nine temporaries are the fixed registers v47-v55 (declared as
@@ -58,8 +59,8 @@ def check(text, probe_waves=False, expect_loops=True):
             loop_temps += 1
         if not re.search(r"\bm0\b", t) or t.startswith("."):
             continue
-        if any(p.match(t) for p in OURS):
-            counters += 1
+        if in_asm and (any(p.match(t) for p in OURS) or re.match(r"^s_mov_b32 m0, s\d+$", t)):
+            counters += 1               # (s_mov_b32 m0, sN: a loop re-entered at iteration sN, bricks_loop_asm)
         else:
             uses.append(t)
     facts["m0_counter_instructions"] = counters

@@ -185,6 +185,18 @@ static bool host_grid_is_regular(const vk::DenseDev &g)
     return ((g.sx | g.sy | g.sz) & 15) == 0 && g.sx <= 1024 && g.sy <= 1024 && g.sz <= 1024;
 }
 
+// Dense targets without the region level (every 16^3 region holds voxels: the noise volume) have rays of very uneven
+// length; their frames run through vk::render_frames_packed, which packs the rays still under way into full
+// wavefronts between rounds of `pack_budget` iterations.  VOLLY_PACKED=0 / 1 switches it off / on for every regular
+// dense grid, VOLLY_PACK_BUDGET=n sets the round length (A/B runs).
+void choose_frame_kernel(volly_gpu_scene *s)
+{
+    s->packed = !s->is_svo && host_grid_is_regular(s->target) && !s->target.use_regions;
+    if (const char *e = std::getenv("VOLLY_PACKED")) s->packed = !s->is_svo && host_grid_is_regular(s->target) && std::atoi(e) != 0;
+    s->pack_budget = 32;
+    if (const char *e = std::getenv("VOLLY_PACK_BUDGET")) s->pack_budget = (uint32_t)std::max(std::atoi(e), 1);
+}
+
 int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res,
                int64_t l3_first, int64_t l3_count)
 {
@@ -474,7 +486,9 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         all_naive &= (frames[i].flags & (VOLLY_FRAME_NAIVE | VOLLY_FRAME_RAYTRACE)) == VOLLY_FRAME_NAIVE;
     }
     // launches of naive frames only are bound by the output path: 32 x 2 tiles (128-byte row segments); else 8 x 8
-    const int tile_w = all_naive ? vk::kTileNaive : vk::kTileBeam, block_w = tile_w * VK_WAVE_BLOCK, block_h = 64 / tile_w;
+    const bool packed = s->packed && !s->is_svo && !any_raytrace;        // vk::render_frames_packed: blocks of kPackWaves 8 x 8 tiles
+    const int tile_w = packed ? vk::kTileBeam : all_naive ? vk::kTileNaive : vk::kTileBeam;
+    const int block_w = packed ? tile_w * vk::kPackWaves : tile_w * VK_WAVE_BLOCK, block_h = 64 / tile_w;
     const size_t span_rows = (size_t)((th + block_h - 1) / block_h), need_spans = span_rows * (size_t)n;
     const bool no_alloc = fixed_frames != nullptr;
     volly_frame_desc *d_frames = fixed_frames;
@@ -548,7 +562,11 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         HIP_TRY(hipEventRecord(e0, stream));
     }
     dim3 grid((unsigned)((tw + block_w - 1) / block_w), (unsigned)((th + block_h - 1) / block_h), (unsigned)n);
-    if (s->is_svo && all_naive)
+    if (packed && all_naive)
+        hipLaunchKernelGGL(vk::render_frames_packed<true>, grid, dim3(64 * vk::kPackWaves), 0, stream, s->target, s->low, d_frames, d_spans, d_ckpt, o, s->pack_budget);
+    else if (packed)
+        hipLaunchKernelGGL(vk::render_frames_packed<false>, grid, dim3(64 * vk::kPackWaves), 0, stream, s->target, s->low, d_frames, d_spans, d_ckpt, o, s->pack_budget);
+    else if (s->is_svo && all_naive)
         hipLaunchKernelGGL((vk::render_frames<true, false, vk::kTileNaive>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
                            d_spans, d_ckpt, o);
     else if (s->is_svo)
@@ -609,6 +627,7 @@ int volume_gpu_upload(int device, const volly_dense_desc *target, const volly_de
         s->has_low = true;
     }
     if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
+    choose_frame_kernel(s);
     *out = s;
     return VOLLY_OK;
 }
@@ -702,6 +721,7 @@ int volume_gpu_generate_noise(int device, int32_t res, uint32_t seed, uint32_t t
     if (!rc) rc = make_dense(s, lr, lr, lr, nullptr, vox_lo, &s->low);
     if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
     s->has_low = true;
+    choose_frame_kernel(s);
     *out = s;
     return VOLLY_OK;
 }
@@ -962,7 +982,7 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 5: return s->has_low ? s->low.sx : 0;
     case 6: return s->device;
     case 7: return (int64_t)(s->bytes >> 20);
-    case 8: return 0;
+    case 8: return s->packed ? 3 : 0;
     case 9: return s->is_svo ? 0 : s->target.use_regions;
     case 10: return s->svo.nodes ? (int64_t)s->svo.n_nodes : 0;
     case 11: return s->svo.nodes ? (int64_t)s->n_leaves : 0;

@@ -47,6 +47,8 @@ struct DeviceGuard {
 struct volly_gpu_scene {
     int device = 0;
     bool is_svo = false, has_low = false;
+    bool packed = false;            // dense target without the region level: frames run through vk::render_frames_packed
+    uint32_t pack_budget = 32;      // iterations per round of that kernel
     vk::DenseDev target{}, low{};
     vk::SvoDev svo{};
     uint32_t n_leaves = 0;
@@ -85,6 +87,8 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
 // level-3 nodes are the index range [l3_first, l3_first + l3_count) (l3_first < 0: unknown), its occupancy blocks
 int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res,
                int64_t l3_first, int64_t l3_count);
+// which frame kernel a finished scene's launches take (after target / low are known)
+void choose_frame_kernel(volly_gpu_scene *s);
 
 } // namespace vimpl
 

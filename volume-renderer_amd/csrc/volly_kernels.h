@@ -750,24 +750,22 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
 // test, brick offset and load of its word, for the lanes whose brick holds voxels the test of the cell's
 // bit, and the advance (19).  A lane that leaves the grid or samples a voxel records its result under an
 // exec mask and drops out of the loop's live mask.  Fixed registers: v47-v55 temporaries, v56 packed cell, v46 brick key, v44-v45 brick word.
-__device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+// The loop itself, for the active lanes: iterations iter0 .. iter_end - 1 of rays whose position is cur (cx, cy, cz).
+// Returns the iteration number it stopped at (iter_end, or earlier when no lane was left); a lane that left the grid or
+// sampled a voxel has its step count in `steps` (0xffffffff: still live) and the packed cell of a hit in `hitc`
+// (0xffffffff: none).  A live lane's cur is where iteration iter_end starts, so the loop can be re-entered there
+// (render_frames_packed does, with other rays in the lanes).
+__device__ __forceinline__ uint32_t bricks_loop_asm(const DenseDev &g, const Ray &r, float &cx, float &cy, float &cz, uint32_t iter0, uint32_t iter_end,
+                                                    uint32_t &steps, uint32_t &hitc)
 {
-    Hit h;
-    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
-    h.steps = 0;
-    h.index = VOLLY_MISS_INDEX;
-    h.payload = VOLLY_MISS_INDEX;
-    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
-    const uint32_t cap = g.cap;
+    const uint32_t cap = iter_end;
     const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz;
     const uint64_t *occ = g.occ;
-    uint32_t steps = 0xFFFFFFFFu;                         // still live
-    uint32_t hitc = 0xFFFFFFFFu;                          // packed cell of the hit
     uint64_t mask_e, mask_a, mask_c;
     uint32_t tmp;
     asm volatile(
         "s_mov_b64 %[se], exec\n\t"
-        "s_mov_b32 m0, 0\n\t"
+        "s_mov_b32 m0, %[iter0]\n\t"
         "v_mov_b32 v46, -1\n\t"                       // no brick yet
         "v_mov_b32 v44, 0\n\t"
         "v_mov_b32 v45, 0\n"
@@ -840,18 +838,32 @@ __device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, c
         "s_branch 1b\n"
         "9:\n\t"
         "s_mov_b64 exec, %[se]"
-        : [cx] "+v"(h.cx), [cy] "+v"(h.cy), [cz] "+v"(h.cz), [steps] "+v"(steps), [hitc] "+v"(hitc),
+        : [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz), [steps] "+v"(steps), [hitc] "+v"(hitc),
           [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sc] "=&s"(mask_c), [tmp] "=&s"(tmp)
         : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
           [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-          [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [occ] "s"(occ)
+          [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [occ] "s"(occ), [iter0] "s"(iter0)
         : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
     uint32_t iter;
     asm volatile("s_mov_b32 %0, m0" : "=s"(iter));
+    return iter;
+}
+
+__device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, const Ray &r, float ox, float oy, float oz)
+{
+    Hit h;
+    enter_volume(r, ox, oy, oz, g.fsx, g.fsy, g.fsz, h.cx, h.cy, h.cz);
+    h.steps = 0;
+    h.index = VOLLY_MISS_INDEX;
+    h.payload = VOLLY_MISS_INDEX;
+    if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
+    uint32_t steps = 0xFFFFFFFFu;                         // still live
+    uint32_t hitc = 0xFFFFFFFFu;                          // packed cell of the hit
+    const uint32_t iter = bricks_loop_asm(g, r, h.cx, h.cy, h.cz, 0u, g.cap, steps, hitc);
     h.steps = (steps == 0xFFFFFFFFu) ? iter : steps;     // lanes still live left at the iteration cap
     if (hitc != 0xFFFFFFFFu) {
         const uint32_t x = hitc & 1023u, y = (hitc >> 10) & 1023u, z = hitc >> 20;
-        h.index = x + sx * (y + sy * z);
+        h.index = x + (uint32_t)g.sx * (y + (uint32_t)g.sy * z);
         h.payload = h.index;
     }
     return h;
@@ -1471,12 +1483,12 @@ __device__ __forceinline__ Ckpt load_checkpoint(const float *__restrict__ ckpt, 
 }
 
 // main.cpp:256-272 for one pixel, from its checkpoint
-template <bool SVO, bool RAYTRACE, bool NAIVE_ONLY>
-__device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const SvoDev &svo, const DenseDev &low, const volly_frame_desc &fd,
-                                                 const Ckpt &k, int xrel)
+// The serial adds from a pixel's checkpoint to the pixel (main.cpp:282-283) for the six direction sums in
+// hx..lz (NAIVE_ONLY: the three target sums only).
+template <bool NAIVE_ONLY>
+__device__ __forceinline__ void direction_sums_from_checkpoint(const volly_frame_desc &fd, int xrel, float &hx, float &hy, float &hz,
+                                                               float &lx, float &ly, float &lz)
 {
-    PixelOut o;
-    float hx = k.v[0], hy = k.v[1], hz = k.v[2], lx = k.v[3], ly = k.v[4], lz = k.v[5];
 #if VK_ASM_EXTRA && VK_CKPT_STRIDE == 8
     // main.cpp:282-283: lane l of an 8-pixel row segment is l & 7 serial adds past its checkpoint.
     // Which lanes still add in round i is known at compile time (every eighth lane drops out per
@@ -1542,6 +1554,15 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
         lx = lx + fd.xdiff_lo[0]; ly = ly + fd.xdiff_lo[1]; lz = lz + fd.xdiff_lo[2];
     }
 #endif
+}
+
+template <bool SVO, bool RAYTRACE, bool NAIVE_ONLY>
+__device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const SvoDev &svo, const DenseDev &low, const volly_frame_desc &fd,
+                                                 const Ckpt &k, int xrel)
+{
+    PixelOut o;
+    float hx = k.v[0], hy = k.v[1], hz = k.v[2], lx = k.v[3], ly = k.v[4], lz = k.v[5];
+    direction_sums_from_checkpoint<NAIVE_ONLY>(fd, xrel, hx, hy, hz, lx, ly, lz);
     const float hw = normalize_w0(hx, hy, hz);            // main.cpp:260
     const Ray ray_hi = make_ray(hx, hy, hz);
     if constexpr (!SVO && RAYTRACE) {
@@ -1639,6 +1660,151 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
         if (out.steps_hi) out.steps_hi[p] = o.shi;
         if (out.depth) out.depth[p] = o.depth;
         if (out.pt_end) { out.pt_end[3 * p] = o.ex; out.pt_end[3 * p + 1] = o.ey; out.pt_end[3 * p + 2] = o.ez; }
+    }
+}
+
+// ---- the frame kernel for dense targets whose rays have very uneven lengths (VK_PACKED) ----------------
+// In a grid without the region level -- the noise volume: every 16^3 region holds voxels -- ray lengths are
+// geometric: a wavefront of render_frames lives as long as the longest of its 64 rays and spends its vector
+// instructions at 17 of 64 lanes (profiles/r02: config 3).  Here a workgroup of kPackWaves wavefronts renders a
+// block of kPackWaves 8x8 tiles side by side.  Set-up, low-grid pass and the entry into the target grid run tile
+// by tile as in render_frames; the target pass then runs in rounds of `budget` iterations (the assembly loop
+// over the bricks, re-entered), and between rounds the rays still under way are packed through LDS into as few
+// full wavefronts as hold them -- in pixel order, so that neighbouring rays stay neighbours in neighbouring
+// lanes and keep sharing brick words -- while the wavefronts left without rays end.  A ray's arithmetic is
+// untouched: position and direction travel as they are, the ray constants are recomputed by the same make_ray
+// from the same direction, and every ray of the block is at the same iteration number (all start the target pass
+// at iteration 0), so the step count is still the iteration at which the lane leaves.
+// State per ray: position, direction, pixel = 28 bytes; 7 KiB of LDS per workgroup.
+#ifndef VK_PACK_WAVES
+#define VK_PACK_WAVES 4
+#endif
+constexpr int kPackWaves = VK_PACK_WAVES;
+
+// what a finished ray of the target pass leaves behind (render_pixel's tail, main.cpp:262-272): every plane but steps_lo
+__device__ __forceinline__ void store_finished_ray(const DenseDev &target, const volly_frame_desc &fd, const OutDev &out, size_t p,
+                                                   float cx, float cy, float cz, float dx, float dy, float dz, uint32_t steps, uint32_t hitc)
+{
+    uint32_t rgba = 255u, index = VOLLY_MISS_INDEX;
+    float depth = __uint_as_float(0x7F800000u);
+    if (hitc != 0xFFFFFFFFu) {
+        const uint32_t x = hitc & 1023u, y = (hitc >> 10) & 1023u, z = hitc >> 20;
+        index = x + (uint32_t)target.sx * (y + (uint32_t)target.sy * z);
+        rgba = shade(target.vox[index]);
+        const float ddx = cx - fd.origin_hi[0], ddy = cy - fd.origin_hi[1], ddz = cz - fd.origin_hi[2];
+        depth = (ddx * dx + ddy * dy) + ddz * dz;
+    }
+    if (out.rgba8) out.rgba8[p] = rgba;
+    if (out.hit_index) out.hit_index[p] = index;
+    if (out.steps_hi) out.steps_hi[p] = steps;
+    if (out.depth) out.depth[p] = depth;
+    if (out.pt_end) { out.pt_end[3 * p] = cx; out.pt_end[3 * p + 1] = cy; out.pt_end[3 * p + 2] = cz; }
+}
+
+template <bool NAIVE_ONLY>
+__global__ void __launch_bounds__(64 * kPackWaves)
+render_frames_packed(DenseDev target, DenseDev low, const volly_frame_desc *__restrict__ frames, const int2 *__restrict__ spans,
+                     const float *__restrict__ ckpt, OutDev out, uint32_t budget)
+{
+    __shared__ float st[7][64 * kPackWaves];
+    __shared__ uint32_t wave_live[2][kPackWaves];
+    const int f = blockIdx.z;
+    const volly_frame_desc &fd = frames[f];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int xrel = (int)blockIdx.x * (kTileBeam * kPackWaves) + wave * kTileBeam + (lane & (kTileBeam - 1));
+    const int yrel = (int)blockIdx.y * kTileBeam + (lane / kTileBeam);
+    const size_t frame_base = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h;
+    bool live = false;
+    float cx = 0.f, cy = 0.f, cz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    uint32_t pix = 0;
+    if ((xrel < fd.tile_w) & (yrel < fd.tile_h)) {
+        const int2 span = spans[(uint32_t)f * gridDim.y + blockIdx.y];
+        const int tx = (int)blockIdx.x * (kTileBeam * kPackWaves) + wave * kTileBeam;
+        const bool sky = (tx + kTileBeam - 1 < span.x) | (tx > span.y);
+        pix = (uint32_t)yrel * (uint32_t)fd.tile_w + (uint32_t)xrel;
+        PixelOut o;
+        if (!sky) {
+            const Ckpt k = load_checkpoint<NAIVE_ONLY>(ckpt, fd, f, xrel, yrel);
+            float hx = k.v[0], hy = k.v[1], hz = k.v[2], lx = k.v[3], ly = k.v[4], lz = k.v[5];
+            direction_sums_from_checkpoint<NAIVE_ONLY>(fd, xrel, hx, hy, hz, lx, ly, lz);
+            normalize_w0(hx, hy, hz);                     // main.cpp:260
+            const Ray ray_hi = make_ray(hx, hy, hz);
+            float sx, sy, sz;                             // start of the target-grid pass
+            if (NAIVE_ONLY || (fd.flags & VOLLY_FRAME_NAIVE)) {   // main.cpp:261
+                sx = fd.origin_hi[0]; sy = fd.origin_hi[1]; sz = fd.origin_hi[2];
+            } else {                                      // raycast_beamOpt, main.cpp:163-166
+                normalize_w0(lx, ly, lz);
+                const Ray ray_lo = make_ray(lx, ly, lz);
+                const Hit lo = trace_dense(low, ray_lo, fd.origin_lo[0], fd.origin_lo[1], fd.origin_lo[2]);
+                o.slo = lo.steps;
+                sx = fd.scale_lo_to_hi[0] * lo.cx; sy = fd.scale_lo_to_hi[1] * lo.cy; sz = fd.scale_lo_to_hi[2] * lo.cz;
+            }
+            if (__all(ray_is_regular(ray_hi))) {          // (the host launches this kernel for regular grids only)
+                enter_volume(ray_hi, sx, sy, sz, target.fsx, target.fsy, target.fsz, cx, cy, cz);
+                dx = hx; dy = hy; dz = hz;
+                o.ex = cx; o.ey = cy; o.ez = cz;          // an inf / NaN entry fails its first bounds test: a miss that ends here
+                live = fabsf(cx) < 3.0e38f && fabsf(cy) < 3.0e38f && fabsf(cz) < 3.0e38f;
+            } else {                                      // a wavefront with an irregular ray: the checked loop, as in trace_dense
+                const Hit hi = trace_dense_checked<false>(target, ray_hi, sx, sy, sz);
+                o.shi = hi.steps;
+                o.hit = hi.index;
+                o.ex = hi.cx; o.ey = hi.cy; o.ez = hi.cz;
+                if (hi.index != VOLLY_MISS_INDEX) {
+                    o.rgba = shade(target.vox[hi.payload]);
+                    const float ddx = hi.cx - fd.origin_hi[0], ddy = hi.cy - fd.origin_hi[1], ddz = hi.cz - fd.origin_hi[2];
+                    o.depth = (ddx * ray_hi.dx + ddy * ray_hi.dy) + ddz * ray_hi.dz;
+                }
+            }
+        }
+        const size_t p = frame_base + pix;
+        if (out.steps_lo) out.steps_lo[p] = o.slo;
+        if (!live) {
+            if (out.rgba8) out.rgba8[p] = o.rgba;
+            if (out.hit_index) out.hit_index[p] = o.hit;
+            if (out.steps_hi) out.steps_hi[p] = o.shi;
+            if (out.depth) out.depth[p] = o.depth;
+            if (out.pt_end) { out.pt_end[3 * p] = o.ex; out.pt_end[3 * p + 1] = o.ey; out.pt_end[3 * p + 2] = o.ez; }
+        }
+    }
+    // ---- the target pass in rounds; between rounds the live rays of the block are packed into full wavefronts
+    int n_waves = kPackWaves, parity = 0;
+    for (uint32_t iter0 = 0;; parity ^= 1) {
+        const uint64_t mine = __ballot(live);
+        if (lane == 0) wave_live[parity][wave] = (uint32_t)__popcll(mine);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+        for (int w = 0; w < n_waves; ++w) {               // (wavefronts >= n_waves have ended)
+            const uint32_t c = wave_live[parity][w];
+            if (w < wave) base += c;
+            total += c;
+        }
+        if (total == 0) return;
+        if (live) {
+            const uint32_t slot = base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+            st[0][slot] = cx; st[1][slot] = cy; st[2][slot] = cz;
+            st[3][slot] = dx; st[4][slot] = dy; st[5][slot] = dz;
+            st[6][slot] = __uint_as_float(pix);
+        }
+        __syncthreads();
+        n_waves = (int)((total + 63u) >> 6);
+        if (wave >= n_waves) return;                      // no rays left for this wavefront
+        const uint32_t slot = (uint32_t)wave * 64u + (uint32_t)lane;
+        live = slot < total;
+        const uint32_t iter_end = (iter0 + budget < target.cap && iter0 + budget > iter0) ? iter0 + budget : target.cap;
+        if (live) {
+            cx = st[0][slot]; cy = st[1][slot]; cz = st[2][slot];
+            dx = st[3][slot]; dy = st[4][slot]; dz = st[5][slot];
+            pix = __float_as_uint(st[6][slot]);
+            const Ray r = make_ray(dx, dy, dz);
+            uint32_t steps = 0xFFFFFFFFu, hitc = 0xFFFFFFFFu;
+            const uint32_t iter = bricks_loop_asm(target, r, cx, cy, cz, iter0, iter_end, steps, hitc);
+            if (steps == 0xFFFFFFFFu && iter_end >= target.cap) steps = iter;     // still live at the iteration cap: a miss with that many steps
+            if (steps != 0xFFFFFFFFu) {
+                store_finished_ray(target, fd, out, frame_base + pix, cx, cy, cz, dx, dy, dz, steps, hitc);
+                live = false;
+            }
+        }
+        iter0 = iter_end;
     }
 }
 

@@ -1030,7 +1030,7 @@ extern "C" int volume_gpu_voxelize(int device, const volly_mesh_desc *mesh, int3
     if (!g.ok) { destroy(s); return fail(VOLLY_E_HIP, "hipSetDevice failed"); }
     rc = voxelize(s, mesh, res, flags, stats);
     if (rc) { std::string keep = g_err; destroy(s); g_err = keep; return rc; }
-
+    choose_frame_kernel(s);
     *out = s;
     return VOLLY_OK;
 }
@@ -1062,7 +1062,7 @@ extern "C" int volume_gpu_voxelize_lod_set(int device, const volly_mesh_desc *me
         return rc;
     }
     for (int i = 0; i < 4; ++i)
-        if (s[i]) out[i] = s[i];
+        if (s[i]) { choose_frame_kernel(s[i]); out[i] = s[i]; }
     return VOLLY_OK;
 }
 
