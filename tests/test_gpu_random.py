@@ -156,7 +156,7 @@ def test_random_octree(vra, ora, case):
     scene.close()
 
 
-PACKED_CASES = list(range(int(os.environ.get("VOLLY_RANDOM_PACKED_CASES", "20"))))
+PACKED_CASES = list(range(int(os.environ.get("VOLLY_RANDOM_PACKED_CASES", "30"))))
 
 
 @pytest.mark.parametrize("case", PACKED_CASES)
@@ -170,6 +170,9 @@ def test_random_dense_packed_kernel(vra, ora, case, monkeypatch):
     budget = [1, 2, 5, 16, 32, 100000][case % 6]
     monkeypatch.setenv("VOLLY_PACKED", "1")
     monkeypatch.setenv("VOLLY_PACK_BUDGET", str(budget))
+    passes, pass_len = [(1, 96), (3, 1), (6, 7), (32, 3), (6, 96)][case % 5]      # rays parked and pooled between passes: never, after every few iterations, as shipped
+    monkeypatch.setenv("VOLLY_PACK_PASSES", str(passes))
+    monkeypatch.setenv("VOLLY_PACK_PASS_LEN", str(pass_len))
     shape = tuple(int(16 * rng.integers(1, 5)) for _ in range(3))
     density = [0.0, 0.001, 0.01, 0.1][(case // 2) % 4]
     vox = _random_grid(rng, shape, density, blobs=int(rng.integers(0, 3)))
@@ -201,7 +204,7 @@ def test_random_dense_packed_kernel(vra, ora, case, monkeypatch):
     five = gpu.render(frames)
     for i, f in enumerate(frames):
         want = ora.render_frame(f, low=scene.low, target=scene.target, planes=ALL)
-        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"packed case {case} frame {i} shape {shape} budget {budget}")
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"packed case {case} frame {i} shape {shape} budget {budget} passes {passes} x {pass_len}")
         assert_planes_equal({k: v[i] for k, v in five.items()}, want, f"packed case {case} frame {i} shape {shape} budget {budget}, five planes")
     gpu.close()
     scene.close()

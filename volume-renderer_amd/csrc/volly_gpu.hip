@@ -33,6 +33,7 @@ static __device__ __align__(256) unsigned char scratch[kNoAllocDescBytes + kNoAl
 using namespace vimpl;
 
 namespace {
+constexpr size_t kDirectHostBytes = (size_t)4 << 20;   // volume_gpu_render: calls of at most this many output bytes store straight into pinned host memory
 constexpr int kFrameChunk = 64;     // most frames per launch (larger launches run closer to the kernel's steady rate: DESIGN.md section 5a)
 static_assert(sizeof(volly_frame_desc) * vk::kInlineFrames <= kNoAllocDescBytes, "descriptor part of the static scratch");
 
@@ -157,6 +158,7 @@ void destroy(volly_gpu_scene *s)
     if (s->d_ckpt) (void)hipFree(s->d_ckpt);
     if (s->d_spans) (void)hipFree(s->d_spans);
     if (s->d_planes) (void)hipFree(s->d_planes);
+    if (s->d_queue) (void)hipFree(s->d_queue);
     if (s->s_render) (void)hipStreamDestroy(s->s_render);
     if (s->s_copy) (void)hipStreamDestroy(s->s_copy);
     delete s;
@@ -195,6 +197,12 @@ void choose_frame_kernel(volly_gpu_scene *s)
     if (const char *e = std::getenv("VOLLY_PACKED")) s->packed = !s->is_svo && host_grid_is_regular(s->target) && std::atoi(e) != 0;
     s->pack_budget = 32;
     if (const char *e = std::getenv("VOLLY_PACK_BUDGET")) s->pack_budget = (uint32_t)std::max(std::atoi(e), 1);
+    // passes (render_chunk): the rays still under way after VOLLY_PACK_PASS_LEN iterations are parked and pooled into
+    // full workgroups for the next pass; VOLLY_PACK_PASSES=1: one pass to the end
+    s->pack_passes = 6;
+    if (const char *e = std::getenv("VOLLY_PACK_PASSES")) s->pack_passes = std::min(std::max(std::atoi(e), 1), 32);
+    s->pack_pass_len = 96;
+    if (const char *e = std::getenv("VOLLY_PACK_PASS_LEN")) s->pack_pass_len = (uint32_t)std::max(std::atoi(e), 1);
 }
 
 int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes, uint32_t n_leaves, int depth, int res,
@@ -562,10 +570,49 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
         HIP_TRY(hipEventRecord(e0, stream));
     }
     dim3 grid((unsigned)((tw + block_w - 1) / block_w), (unsigned)((th + block_h - 1) / block_h), (unsigned)n);
-    if (packed && all_naive)
-        hipLaunchKernelGGL(vk::render_frames_packed<true>, grid, dim3(64 * vk::kPackWaves), 0, stream, s->target, s->low, d_frames, d_spans, d_ckpt, o, s->pack_budget);
-    else if (packed)
-        hipLaunchKernelGGL(vk::render_frames_packed<false>, grid, dim3(64 * vk::kPackWaves), 0, stream, s->target, s->low, d_frames, d_spans, d_ckpt, o, s->pack_budget);
+    if (packed) {
+        // Passes: the first renders the blocks up to iteration bounds[0] and parks the rays still under way; every later
+        // one continues the parked rays, pooled into full workgroups, up to its bound; the last runs them to the end.
+        // A ray that is parked k times is written and read k times (28 bytes).  The entry point that allocates nothing
+        // has no queue: one pass to the end.
+        const size_t n_px = (size_t)n * tw * th;
+        if (n_px >= (1ull << 32)) return fail(VOLLY_E_ARG, "render: more than 2^32 pixels per launch");
+        std::vector<uint32_t> bounds;
+        if (!no_alloc && s->pack_passes > 1) {
+            uint32_t at = 0, len = s->pack_pass_len;
+            for (int i = 0; i + 1 < s->pack_passes && at + len < s->target.cap; ++i) { at += len; bounds.push_back(at); if (i >= 2) len *= 2; }
+        }
+        vk::RayQueue q[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+        if (!bounds.empty()) {
+            if (n_px > s->queue_rays) {
+                if (s->d_queue) { HIP_TRY(hipFree(s->d_queue)); s->d_queue = nullptr; s->queue_rays = 0; }
+                HIP_TRY(hipMalloc(&s->d_queue, 64 + 2 * 7 * n_px * sizeof(float)));
+                s->queue_rays = n_px;
+            }
+            uint32_t *counts = (uint32_t *)s->d_queue;
+            float *items = (float *)((char *)s->d_queue + 64);
+            q[0] = {items, counts, (uint32_t)s->queue_rays};
+            q[1] = {items + 7 * s->queue_rays, counts + 1, (uint32_t)s->queue_rays};
+            HIP_TRY(hipMemsetAsync(counts, 0, 8, stream));
+        }
+        const uint32_t first_bound = bounds.empty() ? 0xFFFFFFFFu : bounds[0];
+        if (all_naive)
+            hipLaunchKernelGGL(vk::render_frames_packed<true>, grid, dim3(64 * vk::kPackWaves), 0, stream, s->target, s->low, d_frames, d_spans, d_ckpt, o,
+                               s->pack_budget, first_bound, q[0]);
+        else
+            hipLaunchKernelGGL(vk::render_frames_packed<false>, grid, dim3(64 * vk::kPackWaves), 0, stream, s->target, s->low, d_frames, d_spans, d_ckpt, o,
+                               s->pack_budget, first_bound, q[0]);
+        HIP_TRY(hipGetLastError());
+        const unsigned cont_blocks = (unsigned)((n_px + 64 * vk::kPackWaves - 1) / (64 * vk::kPackWaves));
+        for (size_t i = 0; i < bounds.size(); ++i) {
+            const int cur = (int)(i & 1);
+            const uint32_t next_bound = i + 1 < bounds.size() ? bounds[i + 1] : 0xFFFFFFFFu;
+            HIP_TRY(hipMemsetAsync(q[cur ^ 1].count, 0, 4, stream));
+            hipLaunchKernelGGL(vk::continue_rays_packed, dim3(cont_blocks), dim3(64 * vk::kPackWaves), 0, stream, s->target, d_frames, (uint32_t)(tw * th), o,
+                               q[cur], bounds[i], s->pack_budget, next_bound, q[cur ^ 1]);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     else if (s->is_svo && all_naive)
         hipLaunchKernelGGL((vk::render_frames<true, false, vk::kTileNaive>), grid, dim3(vk::kFrameThreads), 0, stream, s->target, s->svo, s->low, d_frames,
                            d_spans, d_ckpt, o);
@@ -791,6 +838,34 @@ int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, in
     const size_t words[kPlanes] = {1, 1, 1, 1, 1, 3};      // 4-byte words per pixel
     size_t wanted = 0;
     for (int i = 0; i < kPlanes; ++i) wanted += host[i] ? words[i] : 0;
+    // Output buffers in pinned host memory (volly_gpu_host_alloc, hipHostMalloc, hipHostRegister):
+    // render a few frames at a time on one stream and copy each batch back on another, so the
+    // PCIe transfer of batch k overlaps the traversal of batch k+1.  Pageable buffers take the
+    // plain path below (the runtime stages them through its own pinned buffers).
+    bool pinned = wanted > 0;
+    for (void *h : host) {
+        if (!h) continue;
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, h) != hipSuccess || a.type != hipMemoryTypeHost) { pinned = false; (void)hipGetLastError(); }
+    }
+    // Small calls into pinned memory -- the reference's own call shape, one 400x300 frame per call (main.h:112,
+    // main.cpp:314) -- skip the staging planes altogether: pinned host memory is mapped into the device's address
+    // space, so the frame kernel stores its pixels straight into the caller's buffers over PCIe (0.5 MB takes ~10 us)
+    // and the call is two launches and one synchronisation: no copy, no second stream, no events.
+    if (pinned && wanted * px * 4 <= kDirectHostBytes) {
+        void *devp[kPlanes] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        bool mapped = true;
+        for (int i = 0; i < kPlanes && mapped; ++i)
+            if (host[i] && (hipHostGetDevicePointer(&devp[i], host[i], 0) != hipSuccess || !devp[i])) { mapped = false; (void)hipGetLastError(); }
+        if (mapped) {
+            if (!scene->s_render) HIP_TRY(hipStreamCreateWithFlags(&scene->s_render, hipStreamNonBlocking));
+            volly_outputs direct{(uint32_t *)devp[0], (uint32_t *)devp[1], (uint32_t *)devp[2], (uint32_t *)devp[3], (float *)devp[4], (float *)devp[5]};
+            if ((rc = volume_gpu_render_device(scene, frames, n_frames, &direct, scene->s_render))) return rc;
+            HIP_TRY(hipStreamSynchronize(scene->s_render));
+            return VOLLY_OK;
+        }
+    }
+    // staging planes on the device for everything else
     if (wanted * px * 4 > scene->plane_bytes) {
         if (scene->d_planes) { HIP_TRY(hipFree(scene->d_planes)); scene->d_planes = nullptr; scene->plane_bytes = 0; }
         HIP_TRY(hipMalloc(&scene->d_planes, wanted * px * 4));
@@ -802,16 +877,6 @@ int volume_gpu_render(volly_gpu_scene *scene, const volly_frame_desc *frames, in
         if (host[i]) { dev[i] = (uint32_t *)scene->d_planes + k * px; k += words[i]; }
     volly_outputs d{dev[0], dev[1], dev[2], dev[3], (float *)dev[4], (float *)dev[5]};
 
-    // Output buffers in pinned host memory (volly_gpu_host_alloc, hipHostMalloc, hipHostRegister):
-    // render a few frames at a time on one stream and copy each batch back on another, so the
-    // PCIe transfer of batch k overlaps the traversal of batch k+1.  Pageable buffers take the
-    // plain path below (the runtime stages them through its own pinned buffers).
-    bool pinned = wanted > 0;
-    for (void *h : host) {
-        if (!h) continue;
-        hipPointerAttribute_t a{};
-        if (hipPointerGetAttributes(&a, h) != hipSuccess || a.type != hipMemoryTypeHost) { pinned = false; (void)hipGetLastError(); }
-    }
     if (pinned) {
         if (!scene->s_render) HIP_TRY(hipStreamCreateWithFlags(&scene->s_render, hipStreamNonBlocking));
         if (!scene->s_copy) HIP_TRY(hipStreamCreateWithFlags(&scene->s_copy, hipStreamNonBlocking));

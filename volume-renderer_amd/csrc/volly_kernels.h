@@ -1681,9 +1681,15 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
 #endif
 constexpr int kPackWaves = VK_PACK_WAVES;
 
-// what a finished ray of the target pass leaves behind (render_pixel's tail, main.cpp:262-272): every plane but steps_lo
-__device__ __forceinline__ void store_finished_ray(const DenseDev &target, const volly_frame_desc &fd, const OutDev &out, size_t p,
-                                                   float cx, float cy, float cz, float dx, float dy, float dz, uint32_t steps, uint32_t hitc)
+// Rays parked between two passes of the packed kernels: position, direction and pixel (index into the launch's
+// planes) as seven arrays of `capacity` words, and how many are in it.
+struct RayQueue { float *q; uint32_t *count; uint32_t capacity; };
+
+// what a finished ray of the target pass leaves behind (render_pixel's tail, main.cpp:262-272): every plane but
+// steps_lo.  p: the pixel's index in the launch's planes; its frame (for camPos_Local) is p / frame_px.
+__device__ __forceinline__ void store_finished_ray(const DenseDev &target, const volly_frame_desc *__restrict__ frames, uint32_t frame_px,
+                                                   const OutDev &out, uint32_t p, float cx, float cy, float cz, float dx, float dy, float dz,
+                                                   uint32_t steps, uint32_t hitc)
 {
     uint32_t rgba = 255u, index = VOLLY_MISS_INDEX;
     float depth = __uint_as_float(0x7F800000u);
@@ -1691,6 +1697,7 @@ __device__ __forceinline__ void store_finished_ray(const DenseDev &target, const
         const uint32_t x = hitc & 1023u, y = (hitc >> 10) & 1023u, z = hitc >> 20;
         index = x + (uint32_t)target.sx * (y + (uint32_t)target.sy * z);
         rgba = shade(target.vox[index]);
+        const volly_frame_desc &fd = frames[p / frame_px];
         const float ddx = cx - fd.origin_hi[0], ddy = cy - fd.origin_hi[1], ddz = cz - fd.origin_hi[2];
         depth = (ddx * dx + ddy * dy) + ddz * dz;
     }
@@ -1698,22 +1705,88 @@ __device__ __forceinline__ void store_finished_ray(const DenseDev &target, const
     if (out.hit_index) out.hit_index[p] = index;
     if (out.steps_hi) out.steps_hi[p] = steps;
     if (out.depth) out.depth[p] = depth;
-    if (out.pt_end) { out.pt_end[3 * p] = cx; out.pt_end[3 * p + 1] = cy; out.pt_end[3 * p + 2] = cz; }
+    if (out.pt_end) { out.pt_end[3 * (size_t)p] = cx; out.pt_end[3 * (size_t)p + 1] = cy; out.pt_end[3 * (size_t)p + 2] = cz; }
+}
+
+struct PackShared {
+    float st[7][64 * kPackWaves];
+    uint32_t wave_live[2][kPackWaves];
+    uint32_t queue_base;
+};
+
+// The rounds of one pass for the workgroup's rays (live lanes hold one each: position c, direction d, pixel pix), all at
+// iteration `iter0`: pack, run `budget` iterations, store what finished, until no ray is left or iteration `park_at` is
+// reached -- then the rays still under way are appended to `park` (all at iteration park_at) for the next pass.
+// park_at >= the grid's iteration cap: the pass runs every ray to its end.
+__device__ __forceinline__ void packed_rounds(const DenseDev &target, const volly_frame_desc *__restrict__ frames, uint32_t frame_px, const OutDev &out,
+                                              PackShared &sh, int wave, int lane, bool live, float cx, float cy, float cz, float dx, float dy, float dz,
+                                              uint32_t pix, uint32_t iter0, uint32_t budget, uint32_t park_at, const RayQueue &park)
+{
+    int n_waves = kPackWaves, parity = 0;
+    for (;; parity ^= 1) {
+        const uint64_t mine = __ballot(live);
+        if (lane == 0) sh.wave_live[parity][wave] = (uint32_t)__popcll(mine);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+        for (int w = 0; w < n_waves; ++w) {               // (wavefronts >= n_waves have ended)
+            const uint32_t c = sh.wave_live[parity][w];
+            if (w < wave) base += c;
+            total += c;
+        }
+        if (total == 0) return;
+        const uint32_t rank = base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+        if (iter0 >= park_at) {                           // ---- park: this pass ends here for every ray of the block
+            if (wave == 0 && lane == 0) sh.queue_base = atomicAdd(park.count, total);
+            __syncthreads();
+            if (live) {
+                const size_t slot = (size_t)sh.queue_base + rank, n = park.capacity;
+                park.q[slot] = cx; park.q[n + slot] = cy; park.q[2 * n + slot] = cz;
+                park.q[3 * n + slot] = dx; park.q[4 * n + slot] = dy; park.q[5 * n + slot] = dz;
+                park.q[6 * n + slot] = __uint_as_float(pix);
+            }
+            return;
+        }
+        if (live) {
+            sh.st[0][rank] = cx; sh.st[1][rank] = cy; sh.st[2][rank] = cz;
+            sh.st[3][rank] = dx; sh.st[4][rank] = dy; sh.st[5][rank] = dz;
+            sh.st[6][rank] = __uint_as_float(pix);
+        }
+        __syncthreads();
+        n_waves = (int)((total + 63u) >> 6);
+        if (wave >= n_waves) return;                      // no rays left for this wavefront
+        const uint32_t slot = (uint32_t)wave * 64u + (uint32_t)lane;
+        live = slot < total;
+        uint32_t iter_end = (iter0 + budget > iter0 && iter0 + budget < target.cap) ? iter0 + budget : target.cap;
+        if (iter_end > park_at) iter_end = park_at;
+        if (live) {
+            cx = sh.st[0][slot]; cy = sh.st[1][slot]; cz = sh.st[2][slot];
+            dx = sh.st[3][slot]; dy = sh.st[4][slot]; dz = sh.st[5][slot];
+            pix = __float_as_uint(sh.st[6][slot]);
+            const Ray r = make_ray(dx, dy, dz);
+            uint32_t steps = 0xFFFFFFFFu, hitc = 0xFFFFFFFFu;
+            const uint32_t iter = bricks_loop_asm(target, r, cx, cy, cz, iter0, iter_end, steps, hitc);
+            if (steps == 0xFFFFFFFFu && iter_end >= target.cap) steps = iter;     // still live at the iteration cap: a miss with that many steps
+            if (steps != 0xFFFFFFFFu) {
+                store_finished_ray(target, frames, frame_px, out, pix, cx, cy, cz, dx, dy, dz, steps, hitc);
+                live = false;
+            }
+        }
+        iter0 = iter_end;
+    }
 }
 
 template <bool NAIVE_ONLY>
 __global__ void __launch_bounds__(64 * kPackWaves)
 render_frames_packed(DenseDev target, DenseDev low, const volly_frame_desc *__restrict__ frames, const int2 *__restrict__ spans,
-                     const float *__restrict__ ckpt, OutDev out, uint32_t budget)
+                     const float *__restrict__ ckpt, OutDev out, uint32_t budget, uint32_t park_at, RayQueue park)
 {
-    __shared__ float st[7][64 * kPackWaves];
-    __shared__ uint32_t wave_live[2][kPackWaves];
+    __shared__ PackShared sh;
     const int f = blockIdx.z;
     const volly_frame_desc &fd = frames[f];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int xrel = (int)blockIdx.x * (kTileBeam * kPackWaves) + wave * kTileBeam + (lane & (kTileBeam - 1));
     const int yrel = (int)blockIdx.y * kTileBeam + (lane / kTileBeam);
-    const size_t frame_base = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h;
+    const uint32_t frame_px = (uint32_t)fd.tile_w * (uint32_t)fd.tile_h;          // (a launch holds fewer than 2^32 pixels: render_chunk)
     bool live = false;
     float cx = 0.f, cy = 0.f, cz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
     uint32_t pix = 0;
@@ -1721,7 +1794,7 @@ render_frames_packed(DenseDev target, DenseDev low, const volly_frame_desc *__re
         const int2 span = spans[(uint32_t)f * gridDim.y + blockIdx.y];
         const int tx = (int)blockIdx.x * (kTileBeam * kPackWaves) + wave * kTileBeam;
         const bool sky = (tx + kTileBeam - 1 < span.x) | (tx > span.y);
-        pix = (uint32_t)yrel * (uint32_t)fd.tile_w + (uint32_t)xrel;
+        pix = (uint32_t)f * frame_px + (uint32_t)yrel * (uint32_t)fd.tile_w + (uint32_t)xrel;
         PixelOut o;
         if (!sky) {
             const Ckpt k = load_checkpoint<NAIVE_ONLY>(ckpt, fd, f, xrel, yrel);
@@ -1756,7 +1829,7 @@ render_frames_packed(DenseDev target, DenseDev low, const volly_frame_desc *__re
                 }
             }
         }
-        const size_t p = frame_base + pix;
+        const size_t p = pix;
         if (out.steps_lo) out.steps_lo[p] = o.slo;
         if (!live) {
             if (out.rgba8) out.rgba8[p] = o.rgba;
@@ -1766,46 +1839,29 @@ render_frames_packed(DenseDev target, DenseDev low, const volly_frame_desc *__re
             if (out.pt_end) { out.pt_end[3 * p] = o.ex; out.pt_end[3 * p + 1] = o.ey; out.pt_end[3 * p + 2] = o.ez; }
         }
     }
-    // ---- the target pass in rounds; between rounds the live rays of the block are packed into full wavefronts
-    int n_waves = kPackWaves, parity = 0;
-    for (uint32_t iter0 = 0;; parity ^= 1) {
-        const uint64_t mine = __ballot(live);
-        if (lane == 0) wave_live[parity][wave] = (uint32_t)__popcll(mine);
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-        for (int w = 0; w < n_waves; ++w) {               // (wavefronts >= n_waves have ended)
-            const uint32_t c = wave_live[parity][w];
-            if (w < wave) base += c;
-            total += c;
-        }
-        if (total == 0) return;
-        if (live) {
-            const uint32_t slot = base + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-            st[0][slot] = cx; st[1][slot] = cy; st[2][slot] = cz;
-            st[3][slot] = dx; st[4][slot] = dy; st[5][slot] = dz;
-            st[6][slot] = __uint_as_float(pix);
-        }
-        __syncthreads();
-        n_waves = (int)((total + 63u) >> 6);
-        if (wave >= n_waves) return;                      // no rays left for this wavefront
-        const uint32_t slot = (uint32_t)wave * 64u + (uint32_t)lane;
-        live = slot < total;
-        const uint32_t iter_end = (iter0 + budget < target.cap && iter0 + budget > iter0) ? iter0 + budget : target.cap;
-        if (live) {
-            cx = st[0][slot]; cy = st[1][slot]; cz = st[2][slot];
-            dx = st[3][slot]; dy = st[4][slot]; dz = st[5][slot];
-            pix = __float_as_uint(st[6][slot]);
-            const Ray r = make_ray(dx, dy, dz);
-            uint32_t steps = 0xFFFFFFFFu, hitc = 0xFFFFFFFFu;
-            const uint32_t iter = bricks_loop_asm(target, r, cx, cy, cz, iter0, iter_end, steps, hitc);
-            if (steps == 0xFFFFFFFFu && iter_end >= target.cap) steps = iter;     // still live at the iteration cap: a miss with that many steps
-            if (steps != 0xFFFFFFFFu) {
-                store_finished_ray(target, fd, out, frame_base + pix, cx, cy, cz, dx, dy, dz, steps, hitc);
-                live = false;
-            }
-        }
-        iter0 = iter_end;
+    packed_rounds(target, frames, frame_px, out, sh, wave, lane, live, cx, cy, cz, dx, dy, dz, pix, 0u, budget, park_at, park);
+}
+
+// A later pass: the rays parked by the pass before (all at iteration `iter0`), 64 * kPackWaves of them per workgroup in
+// the order they were parked (a block's rays stay together), through the same rounds.
+__global__ void __launch_bounds__(64 * kPackWaves)
+continue_rays_packed(DenseDev target, const volly_frame_desc *__restrict__ frames, uint32_t frame_px, OutDev out, RayQueue from,
+                     uint32_t iter0, uint32_t budget, uint32_t park_at, RayQueue park)
+{
+    __shared__ PackShared sh;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t count = *from.count, n = from.capacity;
+    const uint32_t i = blockIdx.x * (64u * kPackWaves) + threadIdx.x;          // (the grid covers the queue's capacity: most workgroups end here)
+    if (blockIdx.x * (64u * kPackWaves) >= count) return;
+    const bool live = i < count;
+    float cx = 0.f, cy = 0.f, cz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    uint32_t pix = 0;
+    if (live) {
+        cx = from.q[i]; cy = from.q[n + i]; cz = from.q[2 * (size_t)n + i];
+        dx = from.q[3 * (size_t)n + i]; dy = from.q[4 * (size_t)n + i]; dz = from.q[5 * (size_t)n + i];
+        pix = __float_as_uint(from.q[6 * (size_t)n + i]);
     }
+    packed_rounds(target, frames, frame_px, out, sh, wave, lane, live, cx, cy, cz, dx, dy, dz, pix, iter0, budget, park_at, park);
 }
 
 // ---- scene preparation --------------------------------------------------------
