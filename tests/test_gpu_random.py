@@ -173,6 +173,7 @@ def test_random_dense_packed_kernel(vra, ora, case, monkeypatch):
     passes, pass_len = [(1, 96), (3, 1), (6, 7), (32, 3), (6, 96)][case % 5]      # rays parked and pooled between passes: never, after every few iterations, as shipped
     monkeypatch.setenv("VOLLY_PACK_PASSES", str(passes))
     monkeypatch.setenv("VOLLY_PACK_PASS_LEN", str(pass_len))
+    monkeypatch.setenv("VOLLY_PACK_LOOKAHEAD_FROM", str([1, 2, 9][case % 3]))      # which passes take the look-ahead loop
     shape = tuple(int(16 * rng.integers(1, 5)) for _ in range(3))
     density = [0.0, 0.001, 0.01, 0.1][(case // 2) % 4]
     vox = _random_grid(rng, shape, density, blobs=int(rng.integers(0, 3)))

@@ -195,12 +195,14 @@ void choose_frame_kernel(volly_gpu_scene *s)
 {
     s->packed = !s->is_svo && host_grid_is_regular(s->target) && !s->target.use_regions;
     if (const char *e = std::getenv("VOLLY_PACKED")) s->packed = !s->is_svo && host_grid_is_regular(s->target) && std::atoi(e) != 0;
-    s->pack_budget = 32;
+    s->pack_budget = 48;
     if (const char *e = std::getenv("VOLLY_PACK_BUDGET")) s->pack_budget = (uint32_t)std::max(std::atoi(e), 1);
     // passes (render_chunk): the rays still under way after VOLLY_PACK_PASS_LEN iterations are parked and pooled into
     // full workgroups for the next pass; VOLLY_PACK_PASSES=1: one pass to the end
     s->pack_passes = 6;
     if (const char *e = std::getenv("VOLLY_PACK_PASSES")) s->pack_passes = std::min(std::max(std::atoi(e), 1), 32);
+    s->pack_lookahead_from = 3;      // passes from this one on (the first is 0) run the look-ahead loop
+    if (const char *e = std::getenv("VOLLY_PACK_LOOKAHEAD_FROM")) s->pack_lookahead_from = std::max(std::atoi(e), 1);
     s->pack_pass_len = 96;
     if (const char *e = std::getenv("VOLLY_PACK_PASS_LEN")) s->pack_pass_len = (uint32_t)std::max(std::atoi(e), 1);
 }
@@ -608,8 +610,12 @@ int render_chunk(volly_gpu_scene *s, const volly_frame_desc *frames, int n, size
             const int cur = (int)(i & 1);
             const uint32_t next_bound = i + 1 < bounds.size() ? bounds[i + 1] : 0xFFFFFFFFu;
             HIP_TRY(hipMemsetAsync(q[cur ^ 1].count, 0, 4, stream));
-            hipLaunchKernelGGL(vk::continue_rays_packed, dim3(cont_blocks), dim3(64 * vk::kPackWaves), 0, stream, s->target, d_frames, (uint32_t)(tw * th), o,
-                               q[cur], bounds[i], s->pack_budget, next_bound, q[cur ^ 1]);
+            if ((int)i + 1 >= s->pack_lookahead_from)       // the late passes: few, long rays -- the loop that requests bricks ahead of each ray
+                hipLaunchKernelGGL(vk::continue_rays_packed<true>, dim3(cont_blocks), dim3(64 * vk::kPackWaves), 0, stream, s->target, d_frames, (uint32_t)(tw * th), o,
+                                   q[cur], bounds[i], s->pack_budget, next_bound, q[cur ^ 1]);
+            else
+                hipLaunchKernelGGL(vk::continue_rays_packed<false>, dim3(cont_blocks), dim3(64 * vk::kPackWaves), 0, stream, s->target, d_frames, (uint32_t)(tw * th), o,
+                                   q[cur], bounds[i], s->pack_budget, next_bound, q[cur ^ 1]);
             HIP_TRY(hipGetLastError());
         }
     }

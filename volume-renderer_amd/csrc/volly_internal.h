@@ -48,8 +48,9 @@ struct volly_gpu_scene {
     int device = 0;
     bool is_svo = false, has_low = false;
     bool packed = false;            // dense target without the region level: frames run through vk::render_frames_packed
-    uint32_t pack_budget = 32;      // iterations per round of that kernel
+    uint32_t pack_budget = 48;      // iterations per round of that kernel
     int pack_passes = 6;            // passes of a launch: rays still under way at a pass's end are parked and pooled for the next
+    int pack_lookahead_from = 3;    // passes from this index on use the look-ahead loop (bricks requested ahead of each ray)
     uint32_t pack_pass_len = 96;    // iterations of the first passes (later ones double)
     void *d_queue = nullptr;        // the two queues of parked rays + their counters
     size_t queue_rays = 0;

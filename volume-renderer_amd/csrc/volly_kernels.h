@@ -755,6 +755,125 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
 // sampled a voxel has its step count in `steps` (0xffffffff: still live) and the packed cell of a hit in `hitc`
 // (0xffffffff: none).  A live lane's cur is where iteration iter_end starts, so the loop can be re-entered there
 // (render_frames_packed does, with other rays in the lanes).
+// The text of the loop (a macro, so that the look-ahead form below shares it).  Labels: 1 a step begins: sample point,
+// cell, packed cell, iteration-cap test, brick key; lanes in a new brick: bounds test, leaving lanes record their step
+// count (main.cpp:126-135); 3 the others request their brick's word; 4 lanes whose brick holds voxels test the
+// cell's bit, hits record step count and packed cell (main.cpp:139-142); 6 advance_unit (main.cpp:149-153);
+// 9 the end: no lane left, or the cap.  PREFETCH stands where a lane has just requested the word of a new brick
+// (after it the word must have arrived); EXITWAIT in front of the loop's end.
+#define VK_BRICKS_LOOP_TEXT(PREFETCH, EXITWAIT) \
+        "s_mov_b64 %[se], exec\n\t" \
+        "s_mov_b32 m0, %[iter0]\n\t" \
+        "v_mov_b32 v46, -1\n\t" \
+        "v_mov_b32 v44, 0\n\t" \
+        "v_mov_b32 v45, 0\n" \
+        "1:\n\t" \
+        "v_add_f32 v47, %[cx], %[ex]\n\t" \
+        "v_add_f32 v48, %[cy], %[ey]\n\t" \
+        "v_add_f32 v49, %[cz], %[ez]\n\t" \
+        "v_cvt_i32_f32 v50, v47\n\t" \
+        "v_cvt_i32_f32 v51, v48\n\t" \
+        "v_cvt_i32_f32 v52, v49\n\t" \
+        "v_lshl_or_b32 v56, v51, 10, v50\n\t" \
+        "v_lshl_or_b32 v56, v52, 20, v56\n\t" \
+        "s_cmp_ge_u32 m0, %[cap]\n\t" \
+        "s_cbranch_scc1 9f\n\t" \
+        "v_and_b32 v53, 0xffcff3fc, v56\n\t" \
+        "v_cmp_ne_u32 vcc, v53, v46\n\t" \
+        "s_cbranch_vccz 4f\n\t" \
+        "s_mov_b64 %[sa], exec\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "v_cmp_gt_u32 vcc, %[sx], v50\n\t" \
+        "v_cmp_gt_u32 %[sc], %[sy], v51\n\t" \
+        "s_and_b64 vcc, vcc, %[sc]\n\t" \
+        "v_cmp_gt_u32 %[sc], %[sz], v52\n\t" \
+        "s_and_b64 vcc, vcc, %[sc]\n\t" \
+        "s_andn2_b64 %[sc], exec, vcc\n\t" \
+        "s_cbranch_scc0 3f\n\t" \
+        "s_mov_b64 exec, %[sc]\n\t" \
+        "s_mov_b32 %[tmp], m0\n\t" \
+        "v_mov_b32 %[steps], %[tmp]\n\t" \
+        "s_andn2_b64 %[sa], %[sa], %[sc]\n" \
+        "3:\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "s_cbranch_execz 5f\n\t" \
+        "v_lshrrev_b32 v54, 2, v52\n\t" \
+        "v_and_b32 v55, 0xfffffffc, v51\n\t" \
+        "v_mad_u32_u24 v54, v54, %[sy], v55\n\t" \
+        "v_mul_u32_u24 v54, v54, %[sx]\n\t" \
+        "v_lshrrev_b32 v54, 1, v54\n\t" \
+        "v_lshrrev_b32 v55, 2, v50\n\t" \
+        "v_lshl_add_u32 v54, v55, 3, v54\n\t" \
+        "global_load_dwordx2 v[44:45], v54, %[occ]\n\t" \
+        "v_mov_b32 v46, v53\n\t" \
+        PREFETCH \
+        "5:\n\t" \
+        "s_mov_b64 exec, %[sa]\n\t" \
+        "s_cbranch_execz 9f\n" \
+        "4:\n\t" \
+        "v_cmp_ne_u64 vcc, 0, v[44:45]\n\t" \
+        "s_cbranch_vccz 6f\n\t" \
+        "s_mov_b64 %[sa], exec\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "v_and_b32 v54, 0x300c03, v56\n\t" \
+        "v_mul_u32_u24 v54, 0x40404, v54\n\t" \
+        "v_bfe_u32 v54, v54, 18, 6\n\t" \
+        "v_lshrrev_b64 v[54:55], v54, v[44:45]\n\t" \
+        "v_and_b32 v54, 1, v54\n\t" \
+        "v_cmp_eq_u32 vcc, 1, v54\n\t" \
+        "s_cbranch_vccz 7f\n\t" \
+        "s_mov_b64 exec, vcc\n\t" \
+        "s_add_u32 %[tmp], m0, 1\n\t" \
+        "v_mov_b32 %[steps], %[tmp]\n\t" \
+        "v_mov_b32 %[hitc], v56\n\t" \
+        "s_andn2_b64 %[sa], %[sa], vcc\n" \
+        "7:\n\t" \
+        "s_mov_b64 exec, %[sa]\n\t" \
+        "s_cbranch_execz 9f\n" \
+        "6:\n\t" \
+        VK_ADVANCE_UNIT \
+        "s_add_u32 m0, m0, 1\n\t" \
+        "s_branch 1b\n" \
+        "9:\n\t" \
+        EXITWAIT \
+        "s_mov_b64 exec, %[se]"
+
+// In the plain loop a lane waits for its brick word at once.
+#define VK_BRICKS_WAIT "s_waitcnt vmcnt(0)\n"
+// The look-ahead form, for the passes that continue few, long rays (continue_rays_packed): there the chip is nearly
+// idle and a ray's time is the latency of its dependent brick loads, one per ~2.5 steps, most of them from beyond
+// the L2.  A lane that enters a new brick also requests -- into a register nobody reads -- the brick that holds the
+// point 16 cells further along its ray, clamped into the grid: the ray passes through that point, so when it gets
+// there ~6 bricks later the word is in the L2.  The request changes no result; the lane waits for its own word only
+// (loads return in order: vmcnt(1) leaves the look-ahead request in flight).  17 more vector instructions per brick
+// change: not for the first pass, which is bound by vector issue.
+#define VK_BRICKS_LOOKAHEAD \
+        "v_mul_f32 v53, 0x41800000, %[dx]\n\t" \
+        "v_mul_f32 v54, 0x41800000, %[dy]\n\t" \
+        "v_mul_f32 v55, 0x41800000, %[dz]\n\t" \
+        "v_add_f32 v53, v53, %[cx]\n\t" \
+        "v_add_f32 v54, v54, %[cy]\n\t" \
+        "v_add_f32 v55, v55, %[cz]\n\t" \
+        "v_cvt_i32_f32 v53, v53\n\t" \
+        "v_cvt_i32_f32 v54, v54\n\t" \
+        "v_cvt_i32_f32 v55, v55\n\t" \
+        "s_sub_u32 %[tmp], %[sx], 1\n\t" \
+        "v_med3_i32 v53, v53, 0, %[tmp]\n\t" \
+        "s_sub_u32 %[tmp], %[sy], 1\n\t" \
+        "v_med3_i32 v54, v54, 0, %[tmp]\n\t" \
+        "s_sub_u32 %[tmp], %[sz], 1\n\t" \
+        "v_med3_i32 v55, v55, 0, %[tmp]\n\t" \
+        "v_lshrrev_b32 v55, 2, v55\n\t" \
+        "v_and_b32 v54, 0xfffffffc, v54\n\t" \
+        "v_mad_u32_u24 v55, v55, %[sy], v54\n\t" \
+        "v_mul_u32_u24 v55, v55, %[sx]\n\t" \
+        "v_lshrrev_b32 v55, 1, v55\n\t" \
+        "v_lshrrev_b32 v53, 2, v53\n\t" \
+        "v_lshl_add_u32 v55, v53, 3, v55\n\t" \
+        "global_load_dword v57, v55, %[occ]\n\t" \
+        "s_waitcnt vmcnt(1)\n"
+
+template <bool LOOKAHEAD = false>
 __device__ __forceinline__ uint32_t bricks_loop_asm(const DenseDev &g, const Ray &r, float &cx, float &cy, float &cz, uint32_t iter0, uint32_t iter_end,
                                                     uint32_t &steps, uint32_t &hitc)
 {
@@ -763,81 +882,18 @@ __device__ __forceinline__ uint32_t bricks_loop_asm(const DenseDev &g, const Ray
     const uint64_t *occ = g.occ;
     uint64_t mask_e, mask_a, mask_c;
     uint32_t tmp;
+    if constexpr (LOOKAHEAD)
     asm volatile(
-        "s_mov_b64 %[se], exec\n\t"
-        "s_mov_b32 m0, %[iter0]\n\t"
-        "v_mov_b32 v46, -1\n\t"                       // no brick yet
-        "v_mov_b32 v44, 0\n\t"
-        "v_mov_b32 v45, 0\n"
-        "1:\n\t"                                      // ---- sample point, cell, brick key (exec = live lanes)
-        "v_add_f32 v47, %[cx], %[ex]\n\t"
-        "v_add_f32 v48, %[cy], %[ey]\n\t"
-        "v_add_f32 v49, %[cz], %[ez]\n\t"
-        "v_cvt_i32_f32 v50, v47\n\t"
-        "v_cvt_i32_f32 v51, v48\n\t"
-        "v_cvt_i32_f32 v52, v49\n\t"
-        "v_lshl_or_b32 v56, v51, 10, v50\n\t"
-        "v_lshl_or_b32 v56, v52, 20, v56\n\t"
-        "s_cmp_ge_u32 m0, %[cap]\n\t"
-        "s_cbranch_scc1 9f\n\t"
-        "v_and_b32 v53, 0xffcff3fc, v56\n\t"
-        "v_cmp_ne_u32 vcc, v53, v46\n\t"
-        "s_cbranch_vccz 4f\n\t"
-        "s_mov_b64 %[sa], exec\n\t"                   // sa: the live lanes
-        "s_mov_b64 exec, vcc\n\t"                     // ---- lanes in a new brick
-        "v_cmp_gt_u32 vcc, %[sx], v50\n\t"
-        "v_cmp_gt_u32 %[sc], %[sy], v51\n\t"
-        "s_and_b64 vcc, vcc, %[sc]\n\t"
-        "v_cmp_gt_u32 %[sc], %[sz], v52\n\t"
-        "s_and_b64 vcc, vcc, %[sc]\n\t"               // vcc: new brick inside the grid
-        "s_andn2_b64 %[sc], exec, vcc\n\t"            // sc: outside
-        "s_cbranch_scc0 3f\n\t"
-        "s_mov_b64 exec, %[sc]\n\t"                   // ---- lanes leaving the grid: main.cpp:126-135
-        "s_mov_b32 %[tmp], m0\n\t"
-        "v_mov_b32 %[steps], %[tmp]\n\t"
-        "s_andn2_b64 %[sa], %[sa], %[sc]\n"
-        "3:\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "s_cbranch_execz 5f\n\t"
-        "v_lshrrev_b32 v54, 2, v52\n\t"               // byte offset of the brick word: 8 * (x>>2 + nbx * (y>>2 + nby * (z>>2)))
-        "v_and_b32 v55, 0xfffffffc, v51\n\t"
-        "v_mad_u32_u24 v54, v54, %[sy], v55\n\t"      // 4 * (y>>2 + nby * (z>>2))
-        "v_mul_u32_u24 v54, v54, %[sx]\n\t"           // 16 * nbx * (...)
-        "v_lshrrev_b32 v54, 1, v54\n\t"
-        "v_lshrrev_b32 v55, 2, v50\n\t"
-        "v_lshl_add_u32 v54, v55, 3, v54\n\t"
-        "global_load_dwordx2 v[44:45], v54, %[occ]\n\t"
-        "v_mov_b32 v46, v53\n\t"
-        "s_waitcnt vmcnt(0)\n"
-        "5:\n\t"
-        "s_mov_b64 exec, %[sa]\n\t"
-        "s_cbranch_execz 9f\n"
-        "4:\n\t"                                      // ---- lanes whose brick holds voxels: the cell's bit
-        "v_cmp_ne_u64 vcc, 0, v[44:45]\n\t"
-        "s_cbranch_vccz 6f\n\t"
-        "s_mov_b64 %[sa], exec\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_and_b32 v54, 0x300c03, v56\n\t"
-        "v_mul_u32_u24 v54, 0x40404, v54\n\t"
-        "v_bfe_u32 v54, v54, 18, 6\n\t"
-        "v_lshrrev_b64 v[54:55], v54, v[44:45]\n\t"
-        "v_and_b32 v54, 1, v54\n\t"
-        "v_cmp_eq_u32 vcc, 1, v54\n\t"
-        "s_cbranch_vccz 7f\n\t"
-        "s_mov_b64 exec, vcc\n\t"                     // ---- hits: main.cpp:139-142
-        "s_add_u32 %[tmp], m0, 1\n\t"
-        "v_mov_b32 %[steps], %[tmp]\n\t"
-        "v_mov_b32 %[hitc], v56\n\t"
-        "s_andn2_b64 %[sa], %[sa], vcc\n"
-        "7:\n\t"
-        "s_mov_b64 exec, %[sa]\n\t"
-        "s_cbranch_execz 9f\n"
-        "6:\n\t"                                      // ---- advance_unit (main.cpp:149-153)
-        VK_ADVANCE_UNIT
-        "s_add_u32 m0, m0, 1\n\t"
-        "s_branch 1b\n"
-        "9:\n\t"
-        "s_mov_b64 exec, %[se]"
+        VK_BRICKS_LOOP_TEXT(VK_BRICKS_LOOKAHEAD, "s_waitcnt vmcnt(0)\n\t")
+        : [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz), [steps] "+v"(steps), [hitc] "+v"(hitc),
+          [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sc] "=&s"(mask_c), [tmp] "=&s"(tmp)
+        : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
+          [ix] "v"(r.ix), [iy] "v"(r.iy), [iz] "v"(r.iz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
+          [cap] "s"(cap), [sx] "s"(sx), [sy] "s"(sy), [sz] "s"(sz), [occ] "s"(occ), [iter0] "s"(iter0)
+        : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+    else
+    asm volatile(
+        VK_BRICKS_LOOP_TEXT(VK_BRICKS_WAIT, "")
         : [cx] "+v"(cx), [cy] "+v"(cy), [cz] "+v"(cz), [steps] "+v"(steps), [hitc] "+v"(hitc),
           [se] "=&s"(mask_e), [sa] "=&s"(mask_a), [sc] "=&s"(mask_c), [tmp] "=&s"(tmp)
         : [ex] "v"(r.ex), [ey] "v"(r.ey), [ez] "v"(r.ez), [hx] "v"(r.hx), [hy] "v"(r.hy), [hz] "v"(r.hz),
@@ -1718,6 +1774,7 @@ struct PackShared {
 // iteration `iter0`: pack, run `budget` iterations, store what finished, until no ray is left or iteration `park_at` is
 // reached -- then the rays still under way are appended to `park` (all at iteration park_at) for the next pass.
 // park_at >= the grid's iteration cap: the pass runs every ray to its end.
+template <bool LOOKAHEAD>
 __device__ __forceinline__ void packed_rounds(const DenseDev &target, const volly_frame_desc *__restrict__ frames, uint32_t frame_px, const OutDev &out,
                                               PackShared &sh, int wave, int lane, bool live, float cx, float cy, float cz, float dx, float dy, float dz,
                                               uint32_t pix, uint32_t iter0, uint32_t budget, uint32_t park_at, const RayQueue &park)
@@ -1764,7 +1821,7 @@ __device__ __forceinline__ void packed_rounds(const DenseDev &target, const voll
             pix = __float_as_uint(sh.st[6][slot]);
             const Ray r = make_ray(dx, dy, dz);
             uint32_t steps = 0xFFFFFFFFu, hitc = 0xFFFFFFFFu;
-            const uint32_t iter = bricks_loop_asm(target, r, cx, cy, cz, iter0, iter_end, steps, hitc);
+            const uint32_t iter = bricks_loop_asm<LOOKAHEAD>(target, r, cx, cy, cz, iter0, iter_end, steps, hitc);
             if (steps == 0xFFFFFFFFu && iter_end >= target.cap) steps = iter;     // still live at the iteration cap: a miss with that many steps
             if (steps != 0xFFFFFFFFu) {
                 store_finished_ray(target, frames, frame_px, out, pix, cx, cy, cz, dx, dy, dz, steps, hitc);
@@ -1839,11 +1896,13 @@ render_frames_packed(DenseDev target, DenseDev low, const volly_frame_desc *__re
             if (out.pt_end) { out.pt_end[3 * p] = o.ex; out.pt_end[3 * p + 1] = o.ey; out.pt_end[3 * p + 2] = o.ez; }
         }
     }
-    packed_rounds(target, frames, frame_px, out, sh, wave, lane, live, cx, cy, cz, dx, dy, dz, pix, 0u, budget, park_at, park);
+    packed_rounds<false>(target, frames, frame_px, out, sh, wave, lane, live, cx, cy, cz, dx, dy, dz, pix, 0u, budget, park_at, park);
 }
 
 // A later pass: the rays parked by the pass before (all at iteration `iter0`), 64 * kPackWaves of them per workgroup in
-// the order they were parked (a block's rays stay together), through the same rounds.
+// the order they were parked (a block's rays stay together), through the same rounds.  LOOKAHEAD: with the loop that
+// requests the bricks ahead of each ray (the late passes: few, long rays, bound by load latency).
+template <bool LOOKAHEAD>
 __global__ void __launch_bounds__(64 * kPackWaves)
 continue_rays_packed(DenseDev target, const volly_frame_desc *__restrict__ frames, uint32_t frame_px, OutDev out, RayQueue from,
                      uint32_t iter0, uint32_t budget, uint32_t park_at, RayQueue park)
@@ -1861,7 +1920,7 @@ continue_rays_packed(DenseDev target, const volly_frame_desc *__restrict__ frame
         dx = from.q[3 * (size_t)n + i]; dy = from.q[4 * (size_t)n + i]; dz = from.q[5 * (size_t)n + i];
         pix = __float_as_uint(from.q[6 * (size_t)n + i]);
     }
-    packed_rounds(target, frames, frame_px, out, sh, wave, lane, live, cx, cy, cz, dx, dy, dz, pix, iter0, budget, park_at, park);
+    packed_rounds<LOOKAHEAD>(target, frames, frame_px, out, sh, wave, lane, live, cx, cy, cz, dx, dy, dz, pix, iter0, budget, park_at, park);
 }
 
 // ---- scene preparation --------------------------------------------------------
