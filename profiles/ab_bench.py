@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--mode", default="beam")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--views", type=int, default=None)
+    ap.add_argument("--noise-log2-inv-p", type=int, default=8, help="noise scene: a voxel is filled with probability 2^-n")
     ap.add_argument("--camera", choices=["orbit", "startup", "inside", "fill"], default="orbit", help="bench.py's camera regimes")
     ap.add_argument("--planes", default="rgba8,hit_index,steps_lo,steps_hi,depth", help="output planes written in the timed runs")
     ap.add_argument("variants", nargs="+")
@@ -66,7 +67,7 @@ def main():
             os.environ[e.split("=", 1)[0]] = e.split("=", 1)[1]
         mod = load_variant(name, path)
         if scene is None:
-            g = mod.GpuScene.noise(res, 1, 1 << 24)
+            g = mod.GpuScene.noise(res, 1, 1 << (32 - a.noise_log2_inv_p))
         elif dense:
             g = mod.GpuScene.upload_dense(scene.target, scene.low)
         else:

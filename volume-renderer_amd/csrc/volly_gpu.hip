@@ -117,15 +117,17 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
     d.nrx = (d.nbx + 3) / 4; d.nry = (d.nby + 3) / 4; d.nrz = (d.nbz + 3) / 4;
     const size_t nr = (size_t)d.nrx * d.nry * d.nrz;
     uint64_t *occ2 = nullptr;
-    if ((rc = dev_alloc(s, (void **)&occ2, nr * 8 + 8))) return rc;
-    uint32_t *counter = (uint32_t *)(occ2 + nr);
-    HIP_TRY(hipMemset(counter, 0, 8));
+    if ((rc = dev_alloc(s, (void **)&occ2, nr * 8 + 16))) return rc;
+    uint32_t *counter = (uint32_t *)(occ2 + nr);          // [0] regions that hold voxels; [2..3] filled voxels (64 bit)
+    HIP_TRY(hipMemset(counter, 0, 16));
     hipLaunchKernelGGL(vk::build_occupancy2, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, 0, occ, d.nbx, d.nby, d.nbz, d.nrx,
-                       d.nry, d.nrz, occ2, counter);
+                       d.nry, d.nrz, occ2, counter, (unsigned long long *)(counter + 2));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    uint32_t nonempty = 0;
-    HIP_TRY(hipMemcpy(&nonempty, counter, 4, hipMemcpyDeviceToHost));
+    uint32_t counts[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(counts, counter, 16, hipMemcpyDeviceToHost));
+    const uint32_t nonempty = counts[0];
+    d.n_filled = (uint64_t)counts[2] | ((uint64_t)counts[3] << 32);
     d.occ2 = occ2;
     uint4 *occ2x = nullptr;
     if ((rc = dev_alloc(s, (void **)&occ2x, nr * 16))) return rc;
@@ -193,7 +195,11 @@ static bool host_grid_is_regular(const vk::DenseDev &g)
 // dense grid, VOLLY_PACK_BUDGET=n sets the round length (A/B runs).
 void choose_frame_kernel(volly_gpu_scene *s)
 {
-    s->packed = !s->is_svo && host_grid_is_regular(s->target) && !s->target.use_regions;
+    // ... and only when at least one voxel in 600 is filled: in a sparser volume most rays cross it whole, their lengths
+    // are set by the geometry and a tile's rays end together anyway (p = 1/1024: the tile kernel is 2 % faster,
+    // p = 1/256: the packed one 26 %, p = 1/64: 11 %; profiles/r03_ab/r03_ab_packlen_sweeps.log)
+    const uint64_t cells = (uint64_t)s->target.sx * (uint64_t)s->target.sy * (uint64_t)s->target.sz;
+    s->packed = !s->is_svo && host_grid_is_regular(s->target) && !s->target.use_regions && s->target.n_filled * 600 >= cells;
     if (const char *e = std::getenv("VOLLY_PACKED")) s->packed = !s->is_svo && host_grid_is_regular(s->target) && std::atoi(e) != 0;
     s->pack_budget = 48;
     if (const char *e = std::getenv("VOLLY_PACK_BUDGET")) s->pack_budget = (uint32_t)std::max(std::atoi(e), 1);

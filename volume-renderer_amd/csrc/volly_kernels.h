@@ -132,6 +132,7 @@ struct DenseDev {
     int use_regions;                // consult occ2 (set at upload when most regions are empty; useless for noise)
     float fsx, fsy, fsz;
     uint32_t cap;                   // iteration cap 4*(sx+sy+sz)+8 (the reference has none, main.cpp:121)
+    uint64_t n_filled;              // voxels with a > 0 (counted at upload; the host chooses the frame kernel by the filling)
 };
 
 struct SvoDev {
@@ -1946,19 +1947,23 @@ __global__ void __launch_bounds__(256) build_occupancy(const uint2 *vox, int sx,
 
 // second occupancy level: one word per 4x4x4 bricks, bit set iff the brick holds a voxel
 __global__ void __launch_bounds__(256) build_occupancy2(const uint64_t *occ, int nbx, int nby, int nbz, int nrx, int nry, int nrz,
-                                                        uint64_t *occ2, uint32_t *nonempty_regions)
+                                                        uint64_t *occ2, uint32_t *nonempty_regions, unsigned long long *filled_voxels)
 {
     const size_t rg = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nr = (size_t)nrx * nry * nrz;
     if (rg >= nr) return;
     const int rx = (int)(rg % (size_t)nrx), ry = (int)((rg / (size_t)nrx) % (size_t)nry), rz = (int)(rg / ((size_t)nrx * nry));
     uint64_t bits = 0;
+    unsigned filled = 0;
     for (int k = 0; k < 64; ++k) {
         const int bx = rx * 4 + (k & 3), by = ry * 4 + ((k >> 2) & 3), bz = rz * 4 + (k >> 4);
-        if (bx < nbx && by < nby && bz < nbz && occ[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * (size_t)bz)]) bits |= 1ull << k;
+        if (bx < nbx && by < nby && bz < nbz) {
+            const uint64_t w = occ[(size_t)bx + (size_t)nbx * ((size_t)by + (size_t)nby * (size_t)bz)];
+            if (w) { bits |= 1ull << k; filled += (unsigned)__popcll(w); }
+        }
     }
     occ2[rg] = bits;
-    if (bits) atomicAdd(nonempty_regions, 1u);
+    if (bits) { atomicAdd(nonempty_regions, 1u); atomicAdd(filled_voxels, (unsigned long long)filled); }
 }
 
 // Region entries of the whole-traversal loop: the occ2 word plus, for an empty region, the key mask of
