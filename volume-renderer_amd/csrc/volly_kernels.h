@@ -36,6 +36,7 @@
 //                     the direct-index table of the upper levels
 //   VK_ASM_SVO=0      the compiled loop over the flattened octree (trace_svo_blocks)
 //   VK_SVO_BLOCKS=0   no occupancy blocks for the lowest three octree levels: every locate walks the node chain
+//   VK_SKY_BLOCKS=0   sky tiles store their own pixels (eight 32-byte segments per store) instead of whole 32 x 8 blocks
 //   VK_CKPT_STRIDE=4  a direction checkpoint every 4 pixels instead of 8 (at most 3 instead of 7
 //                     serial adds per lane and component, twice the checkpoint traffic: measured
 //                     1.4 % slower on config 2, 4 % on config 1)
@@ -96,6 +97,9 @@
 #endif
 #ifndef VK_CKPT_STRIDE
 #define VK_CKPT_STRIDE 8
+#endif
+#ifndef VK_SKY_BLOCKS
+#define VK_SKY_BLOCKS 1             // 0: every sky tile stores its own 8 x 8 pixels
 #endif
 
 static_assert(VK_WAVE_BLOCK >= 1, "wavefronts per workgroup");
@@ -1704,6 +1708,25 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
         const int2 span = spans[(uint32_t)f * gridDim.y + blockIdx.y];
         const int tx = (int)blockIdx.x * kBlockW + (VK_WAVE_BLOCK > 1 ? __builtin_amdgcn_readfirstlane(wave) * TW : 0);
         const bool sky = (tx + TW - 1 < span.x) | (tx > span.y);
+#if VK_SKY_BLOCKS
+        if constexpr (TW == kTileBeam && VK_WAVE_BLOCK == 1) {
+            // Four sky tiles side by side (a 32 x 8 block inside the sub-rectangle, all of it outside the span): the first
+            // tile's wavefront writes the whole block, 16 bytes per lane, so that every store instruction fills eight
+            // 128-byte rows instead of eight 32-byte segments; the other three wavefronts have nothing to do.
+            const int bx = tx & ~(4 * TW - 1), ty = (int)blockIdx.y * kBlockH;
+            if ((bx + 4 * TW - 1 < fd.tile_w) & (ty + kBlockH - 1 < fd.tile_h) && ((bx + 4 * TW - 1 < span.x) | (bx > span.y))) {
+                if (tx != bx) return;
+                const size_t q = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)(ty + (lane >> 3)) * (size_t)fd.tile_w + (size_t)(bx + 4 * (lane & 7));
+                const PixelOut miss;
+                if (out.rgba8) *(uint4 *)(out.rgba8 + q) = make_uint4(miss.rgba, miss.rgba, miss.rgba, miss.rgba);
+                if (out.hit_index) *(uint4 *)(out.hit_index + q) = make_uint4(miss.hit, miss.hit, miss.hit, miss.hit);
+                if (out.steps_lo) *(uint4 *)(out.steps_lo + q) = make_uint4(0u, 0u, 0u, 0u);
+                if (out.steps_hi) *(uint4 *)(out.steps_hi + q) = make_uint4(0u, 0u, 0u, 0u);
+                if (out.depth) *(float4 *)(out.depth + q) = make_float4(miss.depth, miss.depth, miss.depth, miss.depth);
+                return;                                   // (pt_end is never requested where tiles are culled: render_chunk)
+            }
+        }
+#endif
         PixelOut o;
         if (!sky) {
             constexpr bool kNaiveOnly = TW == kTileNaive && !RAYTRACE;     // this instantiation serves launches of naive frames only
