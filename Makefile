@@ -78,8 +78,8 @@ tools/_bin/magic_floor: tools/magic_floor.hip
 # alternative builds of the kernels for A/B measurement (profiles/ab_bench.py); never loaded by the product
 VARDIR := $(LIBDIR)/variants
 VARIANTS ?= checked:-DVK_FAST_DDA=0 occ1:-DVK_OCC_LEVELS=1 rootwalk:-DVK_SVO_TABLE=0 waves4:-DVK_WAVE_BLOCK=4 \
-            longdiv:-DVK_SHORT_DIV=0 index32:-DVK_INDEX24=0 ckpt4:-DVK_CKPT_STRIDE=4 packc:-DVK_PACK_ASM=0 noasm:-DVK_ASM_QUIET=0 \
-            noasmextra:-DVK_ASM_EXTRA=0 noasmbricks:-DVK_ASM_BRICKS=0 svocpp:-DVK_ASM_SVO=0 svonodes:-DVK_SVO_BLOCKS=0 nobfi:-DVK_SIGN_BFI=0 w6:-DVK_PROBE_WAVES=6 w4:-DVK_PROBE_WAVES=4 \
+            longdiv:-DVK_SHORT_DIV=0 ckpt4:-DVK_CKPT_STRIDE=4 noasm:-DVK_ASM_QUIET=0 \
+            noasmextra:-DVK_ASM_EXTRA=0 noasmbricks:-DVK_ASM_BRICKS=0 svocpp:-DVK_ASM_SVO=0 svonodes:-DVK_SVO_BLOCKS=0 \
             slp:-fslp-vectorize ahead0:-DVK_RUN_AHEAD=0 count:-DVK_COUNT=1
 variants:
 	@mkdir -p $(VARDIR)

@@ -91,7 +91,7 @@ def check(text, probe_waves=False, expect_loops=True):
 
 def main():
     extra = sys.argv[1:]
-    problems, facts = check(device_assembly(extra), probe_waves=any("VK_PROBE_WAVES" in f or "VK_COUNT" in f for f in extra),
+    problems, facts = check(device_assembly(extra), probe_waves=any("VK_COUNT" in f for f in extra),
                             expect_loops=not any(f.replace(" ", "") == "-DVK_FAST_DDA=0" for f in extra))
     print("kernel contract:", facts)
     for p in problems:

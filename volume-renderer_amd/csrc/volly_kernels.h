@@ -40,15 +40,11 @@
 //   VK_CKPT_STRIDE=4  a direction checkpoint every 4 pixels instead of 8 (at most 3 instead of 7
 //                     serial adds per lane and component, twice the checkpoint traffic: measured
 //                     1.4 % slower on config 2, 4 % on config 1)
-//   VK_INDEX24=0      32-bit multiplies for the brick / region index in the regular loop
-//   VK_PACK_ASM=0     let the compiler choose the instructions that pack a cell
 //   VK_ASM_QUIET=0    the compiled region loop only (no assembly loop for the quiet steps)
 //   VK_RUN_AHEAD=K    steps the region loop takes without looking when every lane is deep inside its empty cube (0: never)
 //   VK_ASM_EXTRA=0    the compiled loop for the serial adds past a checkpoint
 //   VK_ASM_BRICKS=0   the compiled loop for grids without the region level
-//   VK_SIGN_BFI=0     sign(d) * eps by compares, conversion and multiply also for regular wavefronts
 //   VK_SHORT_DIV=0    the compiler's full IEEE expansions of 1/d, sqrt and /255 everywhere
-//   VK_PROBE_WAVES=N  measurement only: N resident wavefronts per SIMD (register padding)
 //   VK_WAVE_BLOCK=N   N wavefronts (N tiles side by side) per workgroup, each storing its tile
 //                     straight from registers: no LDS, no barrier, 1/N of the workgroup dispatches
 // Designs that were measured and rejected in round 1 -- sampling the 8-byte voxels at every step,
@@ -86,15 +82,6 @@
 #ifndef VK_ASM_BRICKS
 #define VK_ASM_BRICKS 1
 #endif
-#ifndef VK_SIGN_BFI
-#define VK_SIGN_BFI 1
-#endif
-#ifndef VK_PACK_ASM
-#define VK_PACK_ASM 1
-#endif
-#ifndef VK_INDEX24
-#define VK_INDEX24 1
-#endif
 #ifndef VK_CKPT_STRIDE
 #define VK_CKPT_STRIDE 8
 #endif
@@ -112,15 +99,7 @@ constexpr int kCkpt = VK_CKPT_STRIDE;   // a direction checkpoint every kCkpt pi
 // launches of naive frames only, which are bound by the output path: 128-byte instead of 32-byte row
 // segments per store (0.64 -> 0.52 ms on the headline frames in naive mode, profiles/r02_ab/ab_tile_shapes.log;
 // in beam mode 16 x 4 is neutral and 32 x 2 is 5-12 % slower).
-#ifndef VK_TILE_NAIVE
-#define VK_TILE_NAIVE 32
-#endif
-constexpr int kTileBeam = 8, kTileNaive = VK_TILE_NAIVE;
-#ifdef VK_PROBE_WAVES            // measurement only: cap the resident wavefronts per SIMD through the register allocation
-#define VK_FRAME_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(VK_PROBE_WAVES, VK_PROBE_WAVES)))
-#else
-#define VK_FRAME_WAVES_ATTR
-#endif
+constexpr int kTileBeam = 8, kTileNaive = 32;       // (64 x 1 for naive launches measured slower: profiles/r03_ab/r03_ab_naive_only.log)
 constexpr int kThreads = 256;
 constexpr int kFrameThreads = 64 * VK_WAVE_BLOCK;   // workgroup size of render_frames
 
@@ -235,12 +214,10 @@ __device__ __forceinline__ Ray make_ray(float dx, float dy, float dz)
     r.hx = (dx < 0.0f) ? 0.0f : 1.0f;
     r.hy = (dy < 0.0f) ? 0.0f : 1.0f;
     r.hz = (dz < 0.0f) ? 0.0f : 1.0f;
-#if VK_SIGN_BFI
     if (__all(r.regular)) {                               // no zero, no NaN: sign(d) * eps is eps with d's sign bit (one v_bfi_b32 each)
         r.ex = __builtin_copysignf(eps, dx); r.ey = __builtin_copysignf(eps, dy); r.ez = __builtin_copysignf(eps, dz);
         return r;
     }
-#endif
     float sx = (float)((0.0f < dx) - (dx < 0.0f));
     float sy = (float)((0.0f < dy) - (dy < 0.0f));
     float sz = (float)((0.0f < dz) - (dz < 0.0f));
@@ -355,25 +332,17 @@ __device__ __forceinline__ uint32_t gather_bits(uint32_t masked)
 // products stay below 2^24 and the 24-bit multiply-add does: 64-bit multiplies are quarter rate)
 __device__ __forceinline__ uint32_t cell_index24(int x, int y, int z, int nx, int ny)
 {
-#if VK_INDEX24
     return __umul24((uint32_t)nx, __umul24((uint32_t)ny, (uint32_t)z) + (uint32_t)y) + (uint32_t)x;
-#else
-    return (uint32_t)x + (uint32_t)nx * ((uint32_t)y + (uint32_t)ny * (uint32_t)z);
-#endif
 }
 
 // x | y << 10 | z << 20 in two v_lshl_or_b32 (left alone the compiler shifts twice and ORs three
 // values: one instruction more in a loop that is bound by instruction issue)
 __device__ __forceinline__ uint32_t pack_cell(int x, int y, int z)
 {
-#if VK_PACK_ASM
     uint32_t t, c;
     asm("v_lshl_or_b32 %0, %1, 10, %2" : "=v"(t) : "v"(y), "v"(x));
     asm("v_lshl_or_b32 %0, %1, 20, %2" : "=v"(c) : "v"(z), "v"(t));
     return c;
-#else
-    return (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
-#endif
 }
 
 __device__ __forceinline__ bool test_word(uint32_t w_lo, uint32_t w_hi, uint32_t bit)
@@ -1687,7 +1656,7 @@ __device__ __forceinline__ PixelOut render_pixel(const DenseDev &target, const S
 // RAYTRACE: the instantiation that can also serve VOLLY_FRAME_RAYTRACE frames (dense targets);
 // it needs 96 VGPRs, so frames of the live path never run through it.
 template <bool SVO, bool RAYTRACE = false, int TW = kTileBeam>
-__global__ void __launch_bounds__(kFrameThreads) VK_FRAME_WAVES_ATTR
+__global__ void __launch_bounds__(kFrameThreads)
 render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc *__restrict__ frames,
               const int2 *__restrict__ spans, const float *__restrict__ ckpt, OutDev out)
 {
@@ -1756,10 +1725,7 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
 // from the same direction, and every ray of the block is at the same iteration number (all start the target pass
 // at iteration 0), so the step count is still the iteration at which the lane leaves.
 // State per ray: position, direction, pixel = 28 bytes; 7 KiB of LDS per workgroup.
-#ifndef VK_PACK_WAVES
-#define VK_PACK_WAVES 4
-#endif
-constexpr int kPackWaves = VK_PACK_WAVES;
+constexpr int kPackWaves = 4;                         // (2, 8 and 16 wavefronts per workgroup measured slower: profiles/r03_ab/r03_ab_packwaves_c3.log)
 
 // Rays parked between two passes of the packed kernels: position, direction and pixel (index into the launch's
 // planes) as seven arrays of `capacity` words, and how many are in it.
