@@ -65,6 +65,21 @@ static int render_all_ways(volly_gpu_scene *sc, int res_hi, int res_lo)
     CHECK(std::memcmp(pin[0], a.rgba.data(), px * 4) == 0 && std::memcmp(pin[1], a.hit.data(), px * 4) == 0);
     CHECK(std::memcmp(pin[5], a.end.data(), px * 12) == 0);
     for (void *p : pin) volly_gpu_host_free(p);
+    {   // (the call above is small enough to store straight into the pinned buffers;) a larger one takes the staged, overlapped path
+        const int W2 = 320, H2 = 200;
+        std::vector<volly_frame_desc> big;
+        frames_for(N, res_hi, res_lo, W2, H2, big);
+        const size_t px2 = (size_t)W2 * H2 * N;
+        void *p0 = volly_gpu_host_alloc(px2 * 4), *p1 = volly_gpu_host_alloc(px2 * 4);
+        CHECK(p0 && p1);
+        volly_outputs o2{(uint32_t *)p0, (uint32_t *)p1, nullptr, nullptr, nullptr, nullptr};
+        CHECK(volume_gpu_render(sc, big.data(), N, &o2) == VOLLY_OK);
+        std::vector<uint32_t> ref(px2);
+        volly_outputs o3{ref.data(), nullptr, nullptr, nullptr, nullptr, nullptr};
+        CHECK(volume_gpu_render(sc, big.data(), N, &o3) == VOLLY_OK);
+        CHECK(std::memcmp(p0, ref.data(), px2 * 4) == 0);
+        volly_gpu_host_free(p0); volly_gpu_host_free(p1);
+    }
 
     volly_outputs only_rgba{b.rgba.data(), nullptr, nullptr, nullptr, nullptr, nullptr};   // one plane, naive frames, a sub-rectangle
     for (auto &f : fr) { f.flags = VOLLY_FRAME_NAIVE; f.x0 = 8; f.y0 = 3; f.tile_w = 40; f.tile_h = 21; }
@@ -117,7 +132,7 @@ static int render_all_ways(volly_gpu_scene *sc, int res_hi, int res_lo)
     CHECK(volume_gpu_render(sc, nullptr, 1, &only_rgba) == VOLLY_E_ARG);
     CHECK(volume_gpu_render(sc, fr.data(), 1, nullptr) == VOLLY_E_ARG);
     CHECK(volume_gpu_render(sc, fr.data(), 1, &only_rgba) == VOLLY_OK);
-    for (int what = -1; what < 16; ++what) (void)volly_gpu_scene_info(sc, what);
+    for (int what = -1; what < 18; ++what) (void)volly_gpu_scene_info(sc, what);
     return 0;
 }
 
@@ -125,7 +140,8 @@ int main(int argc, char **argv)
 {
     if (argc < 2) return 2;
     const std::string assets = argv[1];
-    CHECK(volly_gpu_abi_version() == 2);
+    CHECK(volly_gpu_abi_version() == 3);
+    CHECK(std::strstr(volly_gpu_build_info(), "src_sha16=") != nullptr);
 
     // host scene -> dense upload and octree upload
     volly_host_scene *hs = volly_host_scene_from_mesh((assets + "/teapot.off").c_str(), 64, VOLLY_SCENE_DENSE | VOLLY_SCENE_SVO, 4);
@@ -208,6 +224,7 @@ int main(int argc, char **argv)
     {
         volly_gpu_scene *sc = nullptr;
         CHECK(volume_gpu_generate_noise(0, 64, 1u, 1u << 24, &sc) == VOLLY_OK);
+        CHECK(volly_gpu_scene_info(sc, 8) == 3);           // the packed frame kernel and its queue of parked rays
         if (render_all_ways(sc, 64, 16)) return 1;
         volly_gpu_free(sc);
         CHECK(volume_gpu_generate_noise(0, 30, 1u, 1u << 24, &sc) == VOLLY_E_ARG);

@@ -151,3 +151,20 @@ def test_noalloc_call_under_hip_graph_capture(vra, ora, teapot64):
         assert_planes_equal({k: v[i] for k, v in b.items()}, {k: v[i] for k, v in a.items()}, f"graph replay vs direct call, frame {i}")
     assert_planes_equal({k: v[2] for k, v in b.items()}, ora.render_frame(frames[2], low=teapot64.low, svo=teapot64.svo), "graph replay vs oracle")
     gpu.close()
+
+
+def test_noalloc_on_a_scene_of_the_packed_kernel(vra, ora):
+    """A dense scene without the region level (noise) renders through vk::render_frames_packed; the ordinary entry point
+    parks rays in a queue it allocates between passes, the one that allocates nothing runs one pass to the end: same planes."""
+    import torch
+    gpu = vra.GpuScene.noise(64, 5, 1 << 25)
+    assert gpu.info(8) == 3
+    frames = vra.orbit_frames([0, 3, 7, 11, 13], 24, (64,) * 3, (16,) * 3, 203, 117, radius=1.1)
+    for naive in (False, True):
+        for f in frames:
+            f.flags = 1 if naive else 0
+        want, got = _both(vra, torch, gpu, frames)
+        for i in range(len(frames)):
+            assert_planes_equal({k: v[i] for k, v in got.items()}, {k: v[i] for k, v in want.items()}, f"packed scene, noalloc vs render_device, naive={naive}, frame {i}")
+        assert int((want["hit_index"] != 0xFFFFFFFF).sum()) > 1000 and int(want["steps_hi"].max()) > 100     # rays long enough to be parked
+    gpu.close()
