@@ -1695,6 +1695,28 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
                 return;                                   // (pt_end is never requested where tiles are culled: render_chunk)
             }
         }
+        if constexpr (TW == kTileNaive && VK_WAVE_BLOCK == 1) {
+            // The same for the 32 x 2 tiles of naive launches, stacked: four sky tiles one above the other (each tile row has
+            // its own span) are one 32 x 8 block, written by the topmost tile's wavefront.
+            const int by = (int)blockIdx.y & ~3, ty = by * kBlockH;
+            if ((tx + TW - 1 < fd.tile_w) & (ty + 4 * kBlockH - 1 < fd.tile_h)) {
+                const int2 *sp = spans + (uint32_t)f * gridDim.y + by;
+                const int2 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                const bool all_sky = ((tx + TW - 1 < s0.x) | (tx > s0.y)) & ((tx + TW - 1 < s1.x) | (tx > s1.y)) &
+                                     ((tx + TW - 1 < s2.x) | (tx > s2.y)) & ((tx + TW - 1 < s3.x) | (tx > s3.y));
+                if (all_sky) {
+                    if ((int)blockIdx.y != by) return;
+                    const size_t q = (size_t)f * (size_t)fd.tile_w * (size_t)fd.tile_h + (size_t)(ty + (lane >> 3)) * (size_t)fd.tile_w + (size_t)(tx + 4 * (lane & 7));
+                    const PixelOut miss;
+                    if (out.rgba8) *(uint4 *)(out.rgba8 + q) = make_uint4(miss.rgba, miss.rgba, miss.rgba, miss.rgba);
+                    if (out.hit_index) *(uint4 *)(out.hit_index + q) = make_uint4(miss.hit, miss.hit, miss.hit, miss.hit);
+                    if (out.steps_lo) *(uint4 *)(out.steps_lo + q) = make_uint4(0u, 0u, 0u, 0u);
+                    if (out.steps_hi) *(uint4 *)(out.steps_hi + q) = make_uint4(0u, 0u, 0u, 0u);
+                    if (out.depth) *(float4 *)(out.depth + q) = make_float4(miss.depth, miss.depth, miss.depth, miss.depth);
+                    return;
+                }
+            }
+        }
 #endif
         PixelOut o;
         if (!sky) {
