@@ -8,7 +8,8 @@ profiles/<tag>/:
   each entry stamped with the hash of the library the counters were taken on (lib_sha16, from the bench line
   of the trace run) and the git head at the time of condensing; bench.py ignores entries of another build.
 
-Derived figures (per launch of vk::render_frames<...>):
+Derived figures (per launch of vk::render_frames<...>; a launch of vk::render_frames_packed includes the
+vk::continue_rays_packed passes that follow it):
   cycles            = GRBM_GUI_ACTIVE / 8                       (the counter sums the 8 XCDs)
   hbm_bytes         = (2 * FETCH_SIZE + WRITE_SIZE) * 1024      (MI355X_MICROARCH.md, HBM: gfx950 tallies a
                       128-B read request as 64 B -- doubled; WRITE_SIZE exact; both are taken at the L2's
@@ -41,12 +42,19 @@ for kdir in sorted(glob.glob(os.path.join(src, "*", ""))):
     if not stats:
         continue
     shutil.copy(stats[0], os.path.join(dst, f"{key}_kernel_stats.csv"))
-    kern_ms = None
+    # a launch = one dispatch of the frame kernel plus, for the packed kernel, the passes that continue its parked rays
+    kern_ms, total_ns, first_calls = None, 0.0, 0
     for r in csv.DictReader(open(stats[0])):
         if "render_frames" in r["Name"]:
-            kern_ms = float(r["AverageNs"]) / 1e6
-            kname = r["Name"].split("(")[0]
-            break
+            if kern_ms is None:
+                kname = r["Name"].split("(")[0]
+                first_calls = int(r["Calls"])
+                kern_ms = 0.0
+            total_ns += float(r["TotalDurationNs"])
+        elif "continue_rays_packed" in r["Name"]:
+            total_ns += float(r["TotalDurationNs"])
+    if kern_ms is not None and first_calls:
+        kern_ms = total_ns / first_calls / 1e6
     bench = {}
     try:
         bench = json.loads(open(os.path.join(kdir, "bench_line.json")).readline())
@@ -55,12 +63,16 @@ for kdir in sorted(glob.glob(os.path.join(src, "*", ""))):
         pass
     c = {}
     for f in sorted(glob.glob(os.path.join(kdir, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
-        acc = defaultdict(list)
+        acc, launches = defaultdict(float), defaultdict(int)
         for r in csv.DictReader(open(f)):
             if "render_frames" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
+                launches[r["Counter_Name"]] += 1
+            elif "continue_rays_packed" in r["Kernel_Name"]:      # the later passes of a packed launch count towards that launch
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
         for name, v in acc.items():
-            c[name] = (sum(v) / len(v), len(v))
+            if launches[name]:
+                c[name] = (v / launches[name], launches[name])
     if not c:
         continue
     g = lambda n: c[n][0] if n in c else None
