@@ -36,6 +36,7 @@
 //                     the direct-index table of the upper levels
 //   VK_ASM_SVO=0      the compiled loop over the flattened octree (trace_svo_blocks)
 //   VK_SVO_BLOCKS=0   no occupancy blocks for the lowest three octree levels: every locate walks the node chain
+//   VK_XCD_GROUPS=0   tiles in dispatch order: neighbouring 8 x 8 tiles on different XCDs
 //   VK_SKY_BLOCKS=0   sky tiles store their own pixels (eight 32-byte segments per store) instead of whole 32 x 8 blocks
 //   VK_CKPT_STRIDE=4  a direction checkpoint every 4 pixels instead of 8 (at most 3 instead of 7
 //                     serial adds per lane and component, twice the checkpoint traffic: measured
@@ -84,6 +85,9 @@
 #endif
 #ifndef VK_CKPT_STRIDE
 #define VK_CKPT_STRIDE 8
+#endif
+#ifndef VK_XCD_GROUPS
+#define VK_XCD_GROUPS 4             // tiles side by side per XCD; 0: tile = blockIdx.x (a row chunk's four tiles stored through four XCDs' L2s)
 #endif
 #ifndef VK_SKY_BLOCKS
 #define VK_SKY_BLOCKS 1             // 0: every sky tile stores its own 8 x 8 pixels
@@ -1668,14 +1672,37 @@ render_frames(DenseDev target, SvoDev svo, DenseDev low, const volly_frame_desc 
     // balances sky and object tiles; an XCD-contiguous order measured 12-60 % slower)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int kBlockW = TW * VK_WAVE_BLOCK, kBlockH = 64 / TW;       // workgroup covers VK_WAVE_BLOCK tiles side by side
-    const int xrel = (int)blockIdx.x * kBlockW + wave * TW + (lane & (TW - 1));
+    // Which tile of its row this workgroup renders.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share
+    // one), so with tile = blockIdx.x the four 32-byte segments of a 128-byte row chunk are stored through four different,
+    // mutually incoherent L2s and none of them can merge the chunk: 83 M write requests of 32 bytes per launch instead of
+    // 21 M of 128 (profiles/r03/pmc_summary.csv, TCC_EA0_WRREQ).  With 8 x 8 tiles the columns of a row are therefore taken
+    // in groups of 32: workgroups r, r + 8, r + 16, r + 24 of a group -- one XCD -- render four tiles side by side.  Every
+    // XCD still gets every eighth four-tile chunk of a row, and a different one in the next row (without the rotation a
+    // narrow upright model lands on two of the eight XCDs: config 5 was 2.5 % slower): the load stays balanced, unlike
+    // with an XCD-contiguous order (12-60 % slower in round 1).  Needs a row of a multiple of 8 workgroups, so that a
+    // row's first workgroup always falls on the same XCD; the last, shorter group of a row gives each XCD fewer tiles.
+    int tile_x = (int)blockIdx.x;
+#if VK_XCD_GROUPS
+    if constexpr (TW == kTileBeam && VK_WAVE_BLOCK == 1) {
+        const unsigned gx = gridDim.x, x = blockIdx.x;
+        if ((gx & 7u) == 0u) {
+            constexpr unsigned kG = 8u * VK_XCD_GROUPS;                       // workgroups per group: VK_XCD_GROUPS tiles side by side per XCD
+            const unsigned full = gx - gx % kG;
+            const unsigned base = x < full ? x - x % kG : full;
+            const unsigned k = x < full ? (unsigned)VK_XCD_GROUPS : (gx - full) >> 3;   // tiles per XCD in this group
+            const unsigned r = x - base;
+            tile_x = (int)(base + k * ((r + blockIdx.y) & 7u) + (r >> 3));   // which XCD takes which chunk rotates from row to row
+        }
+    }
+#endif
+    const int xrel = tile_x * kBlockW + wave * TW + (lane & (TW - 1));
     const int yrel = (int)blockIdx.y * kBlockH + (lane / TW);
     if ((xrel < fd.tile_w) & (yrel < fd.tile_h)) {       // eight 32-byte row segments per store instruction
         // Sky tiles: outside its tile row's span (sky_span) every ray is known to end both passes at its
         // first bounds test (0 steps, no hit -- what PixelOut starts as), so the 288-instruction
         // set-up of direction, rays and entry points is skipped.  Wave-uniform: the tile's corner.
         const int2 span = spans[(uint32_t)f * gridDim.y + blockIdx.y];
-        const int tx = (int)blockIdx.x * kBlockW + (VK_WAVE_BLOCK > 1 ? __builtin_amdgcn_readfirstlane(wave) * TW : 0);
+        const int tx = tile_x * kBlockW + (VK_WAVE_BLOCK > 1 ? __builtin_amdgcn_readfirstlane(wave) * TW : 0);
         const bool sky = (tx + TW - 1 < span.x) | (tx > span.y);
 #if VK_SKY_BLOCKS
         if constexpr (TW == kTileBeam && VK_WAVE_BLOCK == 1) {
