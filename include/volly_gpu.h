@@ -247,13 +247,16 @@ int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leav
  * 14 the DDA loop the TARGET grid is traversed with: 0 = octree (not a dense traversal), 1 = the assembly
  *    loop over 16^3 regions and 4^3 bricks, 2 = the assembly loop over bricks only (grids whose regions
  *    nearly all hold voxels), 3 = the fully checked compiled loop -- taken by every grid with an axis
- *    that is not a multiple of 16 or is larger than 1024, measured ~16 % slower; wavefronts holding a
+ *    larger than 1024 (the assembly loops pack a cell into 3 x 10 bits), measured ~16 % slower; sides that
+ *    are no multiple of 16 cost nothing: the occupancy levels cover the grid padded to whole 16^3 regions
+ *    and a ray that samples a cell of the padding has left the grid there; wavefronts holding a
  *    ray with a zero / denormal / NaN direction component take loop 3 whatever the grid,
  * 15 the same for the LOW (beam) grid, 0 = no low grid,
  * 16 octree targets: 1 = traversed through the flattened tree (direct-index table down to 8^3 cells + occupancy
  *    blocks of the lowest three levels, trace_svo_blocks), 0 = through the node chain below the table (trees of
  *    fewer than 3 or more than 11 levels, res not a multiple of 8, nodes not in breadth-first order, stored nodes
- *    without children; wavefronts holding an irregular ray take the node chain whatever the tree). */
+ *    without children; wavefronts holding an irregular ray take the node chain whatever the tree),
+ * 17 dense targets: voxels with a > 0 as counted at upload (the packed kernel is chosen by this filling). */
 int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
 
 /* Sky tiles (no reference counterpart: the reference traces every pixel, main.cpp:252-287).  For one

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--mode", default="beam")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--views", type=int, default=None)
+    ap.add_argument("--res", type=int, default=None, help="voxelize at this side instead of the preset's (e.g. one that is no multiple of 16)")
+    ap.add_argument("--target", choices=["dense", "svo"], default=None, help="target structure instead of the preset's")
     ap.add_argument("--noise-log2-inv-p", type=int, default=8, help="noise scene: a voxel is filled with probability 2^-n")
     ap.add_argument("--camera", choices=["orbit", "startup", "inside", "fill"], default="orbit", help="bench.py's camera regimes")
     ap.add_argument("--planes", default="rgba8,hit_index,steps_lo,steps_hi,depth", help="output planes written in the timed runs")
@@ -40,6 +42,10 @@ def main():
     p["scene"] = p["scene"].split(",")[0]
     if a.views:
         p["views"] = a.views
+    if a.res:
+        p["res"] = a.res
+    if a.target:
+        p["target"] = a.target
     res, W, H, nv = p["res"], p["width"], p["height"], p["views"]
     dense = p["target"] == "dense"
     scene = None

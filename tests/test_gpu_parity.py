@@ -186,12 +186,16 @@ def test_empty_scene_and_errors(vra, ora):
         gpu.close()
 
 
-def test_noise_scene_matches_host_hash(vra, ora):
+@pytest.mark.parametrize("res", [64, 100])
+def test_noise_scene_matches_host_hash(vra, ora, res):
     """volume_gpu_generate_noise: voxels equal the documented hash on the host, the
-    render of the generated scene equals the oracle on a host rebuild of it."""
-    res, seed, thr = 64, 3, 1 << 25
+    render of the generated scene equals the oracle on a host rebuild of it.  (100: a side that is no multiple of 16 --
+    the target and its 25^3 beam grid are traversed on grids padded to whole regions, and the beam grid must not see the
+    padding's cells.)"""
+    seed, thr = 3, 1 << 25
     gpu = vra.GpuScene.noise(res, seed, thr)
     assert gpu.info(8) == 3 and gpu.info(9) == 0      # every region holds voxels: no region level, frames through render_frames_packed
+    assert gpu.info(14) == 2 and gpu.info(15) == 2    # both grids through the assembly brick loop
     dev = gpu.read_voxels(0, res ** 3).reshape(res, res, res, 8)
     z, y, x = np.meshgrid(np.arange(res, dtype=np.uint32), np.arange(res, dtype=np.uint32),
                           np.arange(res, dtype=np.uint32), indexing="ij")
@@ -210,6 +214,7 @@ def test_noise_scene_matches_host_hash(vra, ora):
     host[fill, 5] = ((h >> 16) & 0xFF)[fill]
     host[fill, 6] = ((h >> 24) & 0xFF)[fill]
     assert np.array_equal(dev, host)
+    assert gpu.info(17) == int(fill.sum())            # filled voxels as the library counts them (less the padding's cells)
     low = np.zeros((res // 4,) * 3 + (8,), np.uint8)
     lfill = fill.reshape(res // 4, 4, res // 4, 4, res // 4, 4).any(axis=(1, 3, 5))
     low[lfill, 0:4] = 255

@@ -1,7 +1,8 @@
 """Seeded differential test: random scenes x random cameras x random frame shapes, GPU (through
 the C-ABI) against the oracle, all five planes bit for bit.  The cases are drawn to reach every
-traversal path: grids made of whole 16^3 regions (the regular loop, with and without the region
-level) and grids that are not (the checked loop), octree and dense targets, beam / naive /
+traversal path: grids made of whole 16^3 regions and grids that are not (the assembly loops run on the
+grid padded to whole regions, whose rim cells read as filled: a sample there is where the ray left the
+grid), with and without the region level, octree and dense targets, beam / naive /
 raytrace frames, cameras outside, inside and on cell boundaries, sub-rectangles, axis-parallel
 views (zero direction components) and several frames per call."""
 import numpy as np
@@ -62,6 +63,7 @@ def test_random_scene_camera_frame(vra, ora, case):
     use_svo = cubic_pow2 and case % 8 == 0
     scene = vra.HostScene.from_dense(vox, low, svo=use_svo)
     gpu = vra.GpuScene.upload_svo(scene.svo, scene.low) if use_svo else vra.GpuScene.upload_dense(scene.target, scene.low)
+    assert gpu.info(15) in (1, 2) and (use_svo or gpu.info(14) in (1, 2))      # no grid of these sizes is left to the checked loop
     hi = (shape[2], shape[1], shape[0])
     lo = (low.shape[2], low.shape[1], low.shape[0])
     w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
@@ -162,7 +164,8 @@ PACKED_CASES = list(range(int(os.environ.get("VOLLY_RANDOM_PACKED_CASES", "30"))
 @pytest.mark.parametrize("case", PACKED_CASES)
 def test_random_dense_packed_kernel(vra, ora, case, monkeypatch):
     """vk::render_frames_packed (dense targets without the region level: blocks of four tiles, the rays still under way
-    packed into full wavefronts between rounds) forced onto random regular grids of every filling, with round lengths
+    packed into full wavefronts between rounds) forced onto random grids of every filling and of sides that are and are not
+    multiples of 16, with round lengths
     from 1 iteration (a compaction after every step) to more than any ray takes (none at all): beam and naive frames,
     several per call, odd sizes and sub-rectangles (blocks that hang over the edge), cameras inside and outside, all six
     planes bit for bit against the oracle."""
@@ -175,6 +178,8 @@ def test_random_dense_packed_kernel(vra, ora, case, monkeypatch):
     monkeypatch.setenv("VOLLY_PACK_PASS_LEN", str(pass_len))
     monkeypatch.setenv("VOLLY_PACK_LOOKAHEAD_FROM", str([1, 2, 9][case % 3]))      # which passes take the look-ahead loop
     shape = tuple(int(16 * rng.integers(1, 5)) for _ in range(3))
+    if case % 4 == 1:                                   # sides that are no multiple of 16, 4 or 2: rays leave through rim cells
+        shape = tuple(int(rng.integers(5, 60)) for _ in range(3))
     density = [0.0, 0.001, 0.01, 0.1][(case // 2) % 4]
     vox = _random_grid(rng, shape, density, blobs=int(rng.integers(0, 3)))
     low = _low_of(vox, int(rng.choice([2, 4, 8])))

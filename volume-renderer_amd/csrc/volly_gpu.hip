@@ -103,7 +103,8 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
     vk::DenseDev d{};
     d.vox = vox;
     d.sx = sx; d.sy = sy; d.sz = sz;
-    d.nbx = (sx + 3) / 4; d.nby = (sy + 3) / 4; d.nbz = (sz + 3) / 4;
+    d.px = (sx + 15) & ~15; d.py = (sy + 15) & ~15; d.pz = (sz + 15) & ~15;      // whole 16^3 regions; the rim's cells are set
+    d.nbx = d.px / 4; d.nby = d.py / 4; d.nbz = d.pz / 4;
     d.fsx = (float)sx; d.fsy = (float)sy; d.fsz = (float)sz;
     d.cap = 4u * (uint32_t)(sx + sy + sz) + 8u;
     const size_t nb = (size_t)d.nbx * d.nby * d.nbz;
@@ -114,7 +115,7 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
                        d.nbz, occ);
     HIP_TRY(hipGetLastError());
     d.occ = occ;
-    d.nrx = (d.nbx + 3) / 4; d.nry = (d.nby + 3) / 4; d.nrz = (d.nbz + 3) / 4;
+    d.nrx = d.px / 16; d.nry = d.py / 16; d.nrz = d.pz / 16;
     const size_t nr = (size_t)d.nrx * d.nry * d.nrz;
     uint64_t *occ2 = nullptr;
     if ((rc = dev_alloc(s, (void **)&occ2, nr * 8 + 16))) return rc;
@@ -127,7 +128,7 @@ int make_dense(volly_gpu_scene *s, int sx, int sy, int sz, const void *host_vox,
     uint32_t counts[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(counts, counter, 16, hipMemcpyDeviceToHost));
     const uint32_t nonempty = counts[0];
-    d.n_filled = (uint64_t)counts[2] | ((uint64_t)counts[3] << 32);
+    d.n_filled = ((uint64_t)counts[2] | ((uint64_t)counts[3] << 32)) - ((uint64_t)d.px * d.py * d.pz - (uint64_t)n);   // less the rim
     d.occ2 = occ2;
     uint4 *occ2x = nullptr;
     if ((rc = dev_alloc(s, (void **)&occ2x, nr * 16))) return rc;
@@ -186,7 +187,7 @@ int new_scene(int device, volly_gpu_scene **out)
 
 static bool host_grid_is_regular(const vk::DenseDev &g)
 {
-    return ((g.sx | g.sy | g.sz) & 15) == 0 && g.sx <= 1024 && g.sy <= 1024 && g.sz <= 1024;
+    return g.px <= 1024 && g.py <= 1024 && g.pz <= 1024;
 }
 
 // Dense targets without the region level (every 16^3 region holds voxels: the noise volume) have rays of very uneven
@@ -774,7 +775,7 @@ int volume_gpu_generate_noise(int device, int32_t res, uint32_t seed, uint32_t t
     const size_t nl = (size_t)lr * lr * lr;
     if (!rc) rc = dev_alloc(s, (void **)&vox_lo, nl * 8);
     if (!rc) {
-        hipLaunchKernelGGL(vk::reduce_low, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, 0, s->target.occ, lr, lr, lr, vox_lo);
+        hipLaunchKernelGGL(vk::reduce_low, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, 0, s->target.occ, lr, lr, lr, s->target.nbx, s->target.nby, vox_lo);
         if (hipGetLastError() != hipSuccess) rc = fail(VOLLY_E_HIP, "reduce_low launch failed");
     }
     if (!rc) rc = make_dense(s, lr, lr, lr, nullptr, vox_lo, &s->low);
@@ -1068,6 +1069,7 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 14: return s->is_svo ? 0 : dda_loop_of(s->target);
     case 15: return s->has_low ? dda_loop_of(s->low) : 0;
     case 16: return s->is_svo ? s->svo.use_blocks : 0;
+    case 17: return s->is_svo ? 0 : (int64_t)s->target.n_filled;
     default: return -1;
     }
 }

@@ -114,8 +114,11 @@ struct DenseDev {
                                     // what the whole-traversal loop loads on a region change (build_region_cubes)
     const uint2 *vox;               // the reference's 8-byte voxels, x + sx*(y + sy*z)
     int sx, sy, sz;
-    int nbx, nby, nbz;              // bricks per axis
-    int nrx, nry, nrz;              // 16^3 regions per axis
+    int px, py, pz;                 // the sizes rounded up to whole 16^3 regions: what occ / occ2 / occ2x cover.  The cells of
+                                    // the rim between (sx, sy, sz) and (px, py, pz) are SET in occ: a sample there looks like a
+                                    // hit to the fast loops, which is how they notice that the ray has left the grid (rim_exit)
+    int nbx, nby, nbz;              // bricks per axis (px / 4 ...)
+    int nrx, nry, nrz;              // 16^3 regions per axis (px / 16 ...)
     int use_regions;                // consult occ2 (set at upload when most regions are empty; useless for noise)
     float fsx, fsy, fsz;
     uint32_t cap;                   // iteration cap 4*(sx+sy+sz)+8 (the reference has none, main.cpp:121)
@@ -321,8 +324,16 @@ __device__ __forceinline__ bool ray_is_regular(const Ray &r) { return r.regular;
 
 __device__ __forceinline__ bool grid_is_regular(const DenseDev &g)
 {
-    // whole 16^3 regions only (none straddles the grid's upper faces) and coordinates that fit 10 bits
-    return ((g.sx | g.sy | g.sz) & 15) == 0 && g.sx <= 1024 && g.sy <= 1024 && g.sz <= 1024;
+    // coordinates that fit 10 bits (the occupancy levels always cover whole 16^3 regions: DenseDev::px)
+    return g.px <= 1024 && g.py <= 1024 && g.pz <= 1024;
+}
+
+// The fast loops run on the padded grid (px, py, pz), whose rim cells are set.  A "hit" they report in a rim cell is
+// the sample at which the reference's bounds test fails (main.cpp:126-135): the ray left the grid there, one step
+// count less than a hit's (which counts its own sample, main.cpp:137), no voxel.  Returns true for such a cell.
+__device__ __forceinline__ bool rim_exit(const DenseDev &g, uint32_t x, uint32_t y, uint32_t z)
+{
+    return !((x < (uint32_t)g.sx) & (y < (uint32_t)g.sy) & (z < (uint32_t)g.sz));
 }
 
 // bit index x&3 | (y&3)<<2 | (z&3)<<4 of a cell packed as x | y<<10 | z<<20 (fields already
@@ -392,7 +403,7 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
         if (iter >= g.cap) { h.steps = iter; break; }    // uniform
         uint32_t region = c & 0xFF0FC3F0u;
         if (REGIONS && region != last_region) {
-            bool inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
+            bool inside = ((uint32_t)x < (uint32_t)g.px) & ((uint32_t)y < (uint32_t)g.py) & ((uint32_t)z < (uint32_t)g.pz);
             if (inside) {
                 uint64_t bits = g.occ2[cell_index24(x >> 4, y >> 4, z >> 4, g.nrx, g.nry)];
                 r_lo = (uint32_t)bits;
@@ -410,7 +421,7 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
                 uint32_t brick = c & 0xFFCFF3FCu;
                 bool inside = true;
                 if (brick != last_brick) {
-                    if (!REGIONS) inside = ((uint32_t)x < (uint32_t)g.sx) & ((uint32_t)y < (uint32_t)g.sy) & ((uint32_t)z < (uint32_t)g.sz);
+                    if (!REGIONS) inside = ((uint32_t)x < (uint32_t)g.px) & ((uint32_t)y < (uint32_t)g.py) & ((uint32_t)z < (uint32_t)g.pz);
                     if (inside) {
                         uint64_t bits = g.occ[cell_index24(x >> 2, y >> 2, z >> 2, g.nbx, g.nby)];
                         w_lo = (uint32_t)bits;
@@ -423,9 +434,13 @@ __device__ __forceinline__ Hit trace_dense_regular(const DenseDev &g, const Ray 
                 }
                 if (inside && test_word(w_lo, w_hi, gather_bits(c & 0x00300C03u))) {   // main.cpp:139-142
                     live = 0;
-                    h.steps = iter + 1;
-                    h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
-                    h.payload = h.index;
+                    if (rim_exit(g, (uint32_t)x, (uint32_t)y, (uint32_t)z)) {
+                        h.steps = iter;
+                    } else {
+                        h.steps = iter + 1;
+                        h.index = (uint32_t)x + (uint32_t)g.sx * ((uint32_t)y + (uint32_t)g.sy * (uint32_t)z);
+                        h.payload = h.index;
+                    }
                 }
             }
         }
@@ -521,7 +536,7 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
     h.payload = VOLLY_MISS_INDEX;
     if (!(fabsf(h.cx) < 3.0e38f && fabsf(h.cy) < 3.0e38f && fabsf(h.cz) < 3.0e38f)) return h;   // inf/NaN entry: the first bounds test fails
     const uint32_t cap = g.cap;
-    const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz;
+    const uint32_t sx = (uint32_t)g.px, sy = (uint32_t)g.py, sz = (uint32_t)g.pz;    // the loop's grid is the padded one
     const uint4 *occ2 = g.occ2x;
     const uint64_t *occ = g.occ;
     uint32_t steps = 0xFFFFFFFFu;                         // still live
@@ -714,8 +729,12 @@ __device__ __forceinline__ Hit trace_dense_regions_whole_asm(const DenseDev &g, 
     h.steps = (steps == 0xFFFFFFFFu) ? iter : steps;     // lanes still live left at the iteration cap
     if (hitc != 0xFFFFFFFFu) {
         const uint32_t x = hitc & 1023u, y = (hitc >> 10) & 1023u, z = hitc >> 20;
-        h.index = x + sx * (y + sy * z);
-        h.payload = h.index;
+        if (rim_exit(g, x, y, z)) {
+            h.steps -= 1;
+        } else {
+            h.index = x + (uint32_t)g.sx * (y + (uint32_t)g.sy * z);
+            h.payload = h.index;
+        }
     }
     return h;
 }
@@ -856,7 +875,7 @@ __device__ __forceinline__ uint32_t bricks_loop_asm(const DenseDev &g, const Ray
                                                     uint32_t &steps, uint32_t &hitc)
 {
     const uint32_t cap = iter_end;
-    const uint32_t sx = (uint32_t)g.sx, sy = (uint32_t)g.sy, sz = (uint32_t)g.sz;
+    const uint32_t sx = (uint32_t)g.px, sy = (uint32_t)g.py, sz = (uint32_t)g.pz;    // the loop's grid is the padded one
     const uint64_t *occ = g.occ;
     uint64_t mask_e, mask_a, mask_c;
     uint32_t tmp;
@@ -897,8 +916,12 @@ __device__ __forceinline__ Hit trace_dense_bricks_whole_asm(const DenseDev &g, c
     h.steps = (steps == 0xFFFFFFFFu) ? iter : steps;     // lanes still live left at the iteration cap
     if (hitc != 0xFFFFFFFFu) {
         const uint32_t x = hitc & 1023u, y = (hitc >> 10) & 1023u, z = hitc >> 20;
-        h.index = x + (uint32_t)g.sx * (y + (uint32_t)g.sy * z);
-        h.payload = h.index;
+        if (rim_exit(g, x, y, z)) {
+            h.steps -= 1;
+        } else {
+            h.index = x + (uint32_t)g.sx * (y + (uint32_t)g.sy * z);
+            h.payload = h.index;
+        }
     }
     return h;
 }
@@ -1790,11 +1813,15 @@ __device__ __forceinline__ void store_finished_ray(const DenseDev &target, const
     float depth = __uint_as_float(0x7F800000u);
     if (hitc != 0xFFFFFFFFu) {
         const uint32_t x = hitc & 1023u, y = (hitc >> 10) & 1023u, z = hitc >> 20;
-        index = x + (uint32_t)target.sx * (y + (uint32_t)target.sy * z);
-        rgba = shade(target.vox[index]);
-        const volly_frame_desc &fd = frames[p / frame_px];
-        const float ddx = cx - fd.origin_hi[0], ddy = cy - fd.origin_hi[1], ddz = cz - fd.origin_hi[2];
-        depth = (ddx * dx + ddy * dy) + ddz * dz;
+        if (rim_exit(target, x, y, z)) {
+            steps -= 1;
+        } else {
+            index = x + (uint32_t)target.sx * (y + (uint32_t)target.sy * z);
+            rgba = shade(target.vox[index]);
+            const volly_frame_desc &fd = frames[p / frame_px];
+            const float ddx = cx - fd.origin_hi[0], ddy = cy - fd.origin_hi[1], ddz = cz - fd.origin_hi[2];
+            depth = (ddx * dx + ddy * dy) + ddz * dz;
+        }
     }
     if (out.rgba8) out.rgba8[p] = rgba;
     if (out.hit_index) out.hit_index[p] = index;
@@ -1965,6 +1992,7 @@ continue_rays_packed(DenseDev target, const volly_frame_desc *__restrict__ frame
 // ---- scene preparation --------------------------------------------------------
 
 // occupancy bricks from the reference's voxels: bit set iff rgba.a > 0 (main.cpp:140)
+// (bricks cover the padded grid: the rim cells beyond sx, sy, sz are set, DenseDev::px)
 __global__ void __launch_bounds__(256) build_occupancy(const uint2 *vox, int sx, int sy, int sz, int nbx, int nby, int nbz,
                                                        uint64_t *occ)
 {
@@ -1978,6 +2006,8 @@ __global__ void __launch_bounds__(256) build_occupancy(const uint2 *vox, int sx,
         if (x < sx && y < sy && z < sz) {
             const uint2 v = vox[(size_t)x + (size_t)sx * ((size_t)y + (size_t)sy * (size_t)z)];
             if ((v.x >> 24) != 0) bits |= 1ull << k;
+        } else {
+            bits |= 1ull << k;
         }
     }
     occ[b] = bits;
@@ -2134,12 +2164,15 @@ __global__ void __launch_bounds__(256) generate_noise(uint2 *vox, int res, uint3
 }
 
 // low grid of a synthetic scene: cell filled (white, zero normal) iff any of its 4^3 voxels is
-__global__ void __launch_bounds__(256) reduce_low(const uint64_t *occ_hi, int nbx, int nby, int nbz, uint2 *vox_lo)
+// (lx, ly, lz: the low grid's sizes = the target's / 4, so none of its cells is a brick with rim cells; nbx, nby: the
+// target's bricks per axis, padded)
+__global__ void __launch_bounds__(256) reduce_low(const uint64_t *occ_hi, int lx, int ly, int lz, int nbx, int nby, uint2 *vox_lo)
 {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nb = (size_t)nbx * nby * nbz;
+    const size_t nb = (size_t)lx * ly * lz;
     if (b >= nb) return;
-    vox_lo[b] = occ_hi[b] ? make_uint2(0xFFFFFFFFu, 0u) : make_uint2(0u, 0u);
+    const size_t x = b % (size_t)lx, y = (b / (size_t)lx) % (size_t)ly, z = b / ((size_t)lx * ly);
+    vox_lo[b] = occ_hi[x + (size_t)nbx * (y + (size_t)nby * z)] ? make_uint2(0xFFFFFFFFu, 0u) : make_uint2(0u, 0u);
 }
 
 #endif // VOLLY_TYPES_ONLY
