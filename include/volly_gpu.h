@@ -256,7 +256,10 @@ int volly_gpu_read_svo(volly_gpu_scene *scene, volly_svo_node *nodes, void *leav
  *    blocks of the lowest three levels, trace_svo_blocks), 0 = through the node chain below the table (trees of
  *    fewer than 3 or more than 11 levels, res not a multiple of 8, nodes not in breadth-first order, stored nodes
  *    without children; wavefronts holding an irregular ray take the node chain whatever the tree),
- * 17 dense targets: voxels with a > 0 as counted at upload (the packed kernel is chosen by this filling). */
+ * 17 dense targets: voxels with a > 0 as counted at upload (the packed kernel is chosen by this filling),
+ * 18 octree targets traversed through the flattened tree: 1 = a hit's leaf is found by its rank among the voxels of its
+ *    occupancy word (the tree stores the leaves under each 4^3 cell one after the other in tree order -- octant by
+ *    octant, breadth-first builders do), 0 = by walking down from the level-3 node (three more dependent loads). */
 int64_t volly_gpu_scene_info(const volly_gpu_scene *scene, int what);
 
 /* Sky tiles (no reference counterpart: the reference traces every pixel, main.cpp:252-287).  For one

@@ -124,6 +124,7 @@ def test_random_octree(vra, ora, case):
     gpu = vra.GpuScene.upload_svo(scene.svo, scene.low)
     # (an empty tree deeper than three levels has no level-3 node: it takes the node chain)
     assert gpu.info(16) == (1 if res % 8 == 0 and (gpu.info(11) > 0 or res == 8) else 0)
+    assert gpu.info(18) == gpu.info(16)       # the host builder stores leaves in tree order: a hit's leaf is found by rank
     hi, lo = (res,) * 3, (low.shape[2], low.shape[1], low.shape[0])
     w, h = int(rng.integers(8, 120)), int(rng.integers(8, 90))
     frames = []
@@ -156,6 +157,45 @@ def test_random_octree(vra, ora, case):
         assert_planes_equal({k: v[i] for k, v in five.items()}, want, f"octree case {case} frame {i} res {res} flags {f.flags}, five planes")
     gpu.close()
     scene.close()
+
+
+def test_octree_with_leaves_out_of_tree_order(vra, ora):
+    """A valid tree whose leaf array is NOT in tree order (the leaf groups of the level-1 nodes stored back to front):
+    the flattened traversal still applies, but a hit's leaf cannot be found by its rank among the voxels of its
+    occupancy word -- the library must notice at upload (scene_info 18 = 0) and walk down from the level-3 node."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    res = 32
+    vox = _random_grid(rng, (res,) * 3, 0.05, blobs=3)
+    low = _low_of(vox, 4)
+    scene = vra.HostScene.from_dense(vox, low, svo=True)
+    nodes, leaves = scene.svo_arrays()
+    nodes, leaves = nodes.copy(), leaves.copy()
+    l1 = np.flatnonzero(nodes["leaf_mask"] != 0)                      # level-1 nodes, in tree order
+    counts = np.array([bin(int(m)).count("1") for m in nodes["leaf_mask"][l1]])
+    old_start = nodes["child_offset"][l1].astype(np.int64)
+    new_start = len(leaves) - np.cumsum(counts)                       # the first group goes last
+    shuffled = np.empty_like(leaves)
+    for a, b, k in zip(old_start, new_start, counts):
+        shuffled[b:b + k] = leaves[a:a + k]
+    nodes["child_offset"][l1] = new_start.astype(np.uint32)
+    d = scene.svo
+    desc = type(d)(d.n_nodes, d.n_leaves, d.depth, d.res, nodes.ctypes.data, shuffled.ctypes.data)
+    gpu = vra.GpuScene.upload_svo(desc, scene.low)
+    assert gpu.info(16) == 1 and gpu.info(18) == 0
+    ordered = vra.GpuScene.upload_svo(scene.svo, scene.low)
+    assert ordered.info(16) == 1 and ordered.info(18) == 1
+    hi, lo = (res,) * 3, (low.shape[2], low.shape[1], low.shape[0])
+    frames = list(vra.orbit_frames(range(4), 4, hi, lo, 96, 64, radius=0.9)) + list(vra.orbit_frames(range(2), 4, hi, lo, 96, 64, radius=0.3, naive=True))
+    got, ref = gpu.render(frames, planes=ALL), ordered.render(frames, planes=ALL)
+    hits = 0
+    for i, f in enumerate(frames):
+        want = ora.render_frame(f, low=scene.low, svo=desc, planes=ALL)
+        hits += int((want["hit_index"] != MISS).sum())
+        assert_planes_equal({k: v[i] for k, v in got.items()}, want, f"shuffled leaves, frame {i}")
+        assert_planes_equal({k: v[i] for k, v in ref.items()}, want, f"ordered leaves against the shuffled tree's oracle, frame {i}")
+    assert hits > 1000
+    gpu.close(); ordered.close(); scene.close()
 
 
 PACKED_CASES = list(range(int(os.environ.get("VOLLY_RANDOM_PACKED_CASES", "30"))))

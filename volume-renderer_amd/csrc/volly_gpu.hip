@@ -241,21 +241,27 @@ int finish_svo(volly_gpu_scene *s, uint2 *nodes, uint2 *leaves, uint32_t n_nodes
     // occupancy blocks of the lowest three levels (vk::build_svo_blocks): needs the level-3 nodes as one contiguous
     // index range (breadth-first trees have that; the caller says where), table cells of 8^3 and whole 8^3 cells
     // inside the grid.  VOLLY_SVO_BLOCKS=0 keeps the node-chain traversal (A/B runs).
-    s->svo.blocks = nullptr; s->svo.l3_first = 0; s->svo.use_blocks = 0;
+    s->svo.blocks = nullptr; s->svo.word_base = nullptr; s->svo.l3_first = 0; s->svo.use_blocks = 0; s->svo.use_rank = 0;
     bool want = depth >= 3 && s->svo.tshift == 3 && (res & 7) == 0 && l3_first >= 0 && l3_count > 0 && l3_first + l3_count <= (int64_t)n_nodes;
     if (const char *e = std::getenv("VOLLY_SVO_BLOCKS")) want = want && std::atoi(e) != 0;
     if (want) {
         uint64_t *blocks = nullptr;
         if ((rc = dev_alloc(s, (void **)&blocks, (size_t)l3_count * 64 + 8))) return rc;
+        uint32_t *word_base = nullptr;
+        if ((rc = dev_alloc(s, (void **)&word_base, (size_t)l3_count * 32))) return rc;
         uint32_t *bad = (uint32_t *)(blocks + (size_t)l3_count * 8);
         HIP_TRY(hipMemset(bad, 0, 8));
-        hipLaunchKernelGGL(vk::build_svo_blocks, dim3((unsigned)((l3_count + 255) / 256)), dim3(256), 0, 0, nodes, (uint32_t)l3_first, (uint32_t)l3_count, blocks, bad);
+        hipLaunchKernelGGL(vk::build_svo_blocks, dim3((unsigned)((l3_count + 255) / 256)), dim3(256), 0, 0, nodes, (uint32_t)l3_first, (uint32_t)l3_count, blocks,
+                           word_base, bad);
         if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(VOLLY_E_HIP, "build_svo_blocks failed");
-        uint32_t is_bad = 1;
-        HIP_TRY(hipMemcpy(&is_bad, bad, 4, hipMemcpyDeviceToHost));
+        uint32_t is_bad[2] = {1, 1};
+        HIP_TRY(hipMemcpy(is_bad, bad, 8, hipMemcpyDeviceToHost));
         s->svo.blocks = blocks;
+        s->svo.word_base = word_base;
         s->svo.l3_first = (uint32_t)l3_first;
-        s->svo.use_blocks = is_bad ? 0 : 1;      // a stored node without children: the node chain decides (see build_svo_blocks)
+        s->svo.use_blocks = is_bad[0] ? 0 : 1;   // a stored node without children: the node chain decides (see build_svo_blocks)
+        s->svo.use_rank = is_bad[1] ? 0 : 1;     // leaves not in tree order under some word: a hit walks down to its leaf
+        if (const char *e = std::getenv("VOLLY_SVO_LEAF_RANK")) s->svo.use_rank = s->svo.use_rank && std::atoi(e) != 0;      // (A/B runs)
     }
     return VOLLY_OK;
 }
@@ -1070,6 +1076,7 @@ int64_t volly_gpu_scene_info(const volly_gpu_scene *s, int what)
     case 15: return s->has_low ? dda_loop_of(s->low) : 0;
     case 16: return s->is_svo ? s->svo.use_blocks : 0;
     case 17: return s->is_svo ? 0 : (int64_t)s->target.n_filled;
+    case 18: return s->is_svo ? (s->svo.use_blocks && s->svo.use_rank) : 0;
     default: return -1;
     }
 }

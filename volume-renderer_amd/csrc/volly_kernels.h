@@ -131,7 +131,10 @@ struct SvoDev {
     const uint32_t *table;          // upper levels flattened: (2^tbits)^3 entries, see build_svo_table
     const uint64_t *blocks;         // lowest three levels flattened: 8 occupancy words (one per 4^3 octant, the dense bricks' bit
                                     // order) per level-3 node (an 8^3 cell), indexed by node - l3_first; see build_svo_blocks
+    const uint32_t *word_base;      // per block word: index in leaves[] of the first leaf under it (build_svo_blocks)
     uint32_t l3_first;              // index of the first level-3 node (breadth-first order: the nodes of a level are contiguous)
+    int use_rank;                   // the leaves under each block word are stored one after the other in tree order: the leaf
+                                    // of a hit is word_base + its rank among the word's bits (svo_leaf_by_rank), no walk
     int use_blocks;                 // the table ends at 8^3 cells (tshift == 3), blocks are built, res is a multiple of 8: trace_svo_blocks
     int tbits, tshift;              // table cell = octree cell of 2^tshift voxels; tbits + tshift = depth
     uint32_t n_nodes;
@@ -1036,6 +1039,49 @@ __device__ __forceinline__ void advance_cell_folded(const Ray &r, float s, float
 
 __device__ __forceinline__ bool svo_is_regular(const SvoDev &t) { return t.use_blocks != 0; }
 
+// The leaf of the hit voxel (x, y, z) under level-3 node l3, for the flattened tree.  Walking down from the node costs
+// three dependent loads per hit ray -- with the leaf itself, four latencies at the end of every hit wavefront's life,
+// which is what paces the naive frames and the reference's start-up camera (few iterations per ray, every ray a hit).
+// When the tree stores the leaves under a block word one after the other in tree order (use_rank; breadth-first
+// builders do), the leaf is word_base + the number of the word's voxels that come before this one in that order:
+// two independent loads and three popcounts.  Tree order under a word: 2^3 sub-octant (z1 y1 x1), then voxel
+// (z0 y0 x0); the word's bits are x0 x1 y0 y1 z0 z1 (LSB first), so "before" is a mask per sub-octant plus the
+// sub-octant's own lower voxels.
+__device__ __forceinline__ uint32_t svo_leaf_by_walk(const SvoDev &t, uint32_t l3, uint32_t x, uint32_t y, uint32_t z)
+{
+    uint2 n = t.nodes[l3];
+    uint32_t child = 0;
+    #pragma unroll
+    for (int sh = 2; sh >= 0; --sh) {
+        const uint32_t oct = ((x >> sh) & 1u) | (((y >> sh) & 1u) << 1) | (((z >> sh) & 1u) << 2);
+        const uint32_t valid = n.y & 0xFFu, bit = 1u << oct;
+        child = n.x + (uint32_t)__popc(valid & (bit - 1u));
+        if (sh) n = t.nodes[child];
+    }
+    return child;
+}
+
+__device__ __forceinline__ uint32_t svo_leaf_by_rank(const SvoDev &t, uint32_t l3, uint32_t x, uint32_t y, uint32_t z)
+{
+    const uint32_t o4 = ((x >> 2) & 1u) | (((y >> 2) & 1u) << 1) | (((z >> 2) & 1u) << 2);
+    const size_t wi = (size_t)(l3 - t.l3_first) * 8 + o4;
+    const uint32_t base = t.word_base[wi];
+    const uint64_t w = t.blocks[wi];
+    const uint32_t b = (x & 3u) | ((y & 3u) << 2) | ((z & 3u) << 4);
+    // voxels of the sub-octants before this one: within a 32-bit half (one z1), those with (y1, x1) smaller
+    const uint32_t half = ((b & 8u) ? 0x00FF00FFu : 0u) | (((b & 8u) ? 0xFF00FF00u : 0x00FF00FFu) & ((b & 2u) ? 0x33333333u : 0u));
+    const uint32_t lt_lo = (b & 32u) ? 0xFFFFFFFFu : half, lt_hi = (b & 32u) ? half : 0u;
+    // this sub-octant's voxels (offsets 0,1,4,5,16,17,20,21 from its first bit, in voxel order) below the hit one
+    const uint32_t sub = (uint32_t)(w >> (b & 0x2Au)) & 0x00330033u;
+    const uint32_t before = sub & ((1u << (b & 0x15u)) - 1u);
+    return base + (uint32_t)__popc((uint32_t)w & lt_lo) + (uint32_t)__popc((uint32_t)(w >> 32) & lt_hi) + (uint32_t)__popc(before);
+}
+
+__device__ __forceinline__ uint32_t svo_leaf_of_hit(const SvoDev &t, uint32_t l3, uint32_t x, uint32_t y, uint32_t z)
+{
+    return t.use_rank ? svo_leaf_by_rank(t, l3, x, y, z) : svo_leaf_by_walk(t, l3, x, y, z);
+}
+
 // Octree traversal over the flattened tree (VK_SVO_BLOCKS): the same iterations as trace_svo -- every decision and
 // every float equal -- with at most two dependent loads per iteration instead of up to five, and most iterations none:
 //   * upper levels: the direct-index table gives, per 8^3 cell, "empty cell of 2^k voxels" (as the float -(2^k)) or
@@ -1043,7 +1089,7 @@ __device__ __forceinline__ bool svo_is_regular(const SvoDev &t) { return t.use_b
 //   * lowest three levels: the node's block holds one 64-bit occupancy word per 4^3 octant.  word == 0: the octant is
 //     an empty cell of 4 voxels; the 2^3 sub-octant's eight bits clear: an empty cell of 2; else the voxel's own bit
 //     decides between a hit and an empty cell of 1.  A lane keeps the word while it stays in the 4^3 brick.
-// The leaf index of a hit is found afterwards by one walk down from the level-3 node (three loads per hit ray).
+// The leaf index of a hit is found afterwards: svo_leaf_of_hit.
 // Preconditions (svo_is_regular + regular rays, checked by the caller): res a multiple of 8 (so a cell outside the
 // grid never shares its 8^3 key with the cell before it), table cells of 8^3, every direction component regular.
 // Cells are kept as the pair xy = x | y << 16 (saturating conversion: a negative or huge coordinate becomes 0xffff,
@@ -1102,16 +1148,7 @@ __device__ __forceinline__ Hit trace_svo_blocks(const SvoDev &t, const Ray &r, f
     }
     if (hit) {
         h.index = (uint32_t)x + res * ((uint32_t)y + res * (uint32_t)z);
-        uint2 n = t.nodes[l3];
-        uint32_t child = 0;
-        #pragma unroll
-        for (int sh = 2; sh >= 0; --sh) {
-            const uint32_t oct = (((uint32_t)x >> sh) & 1u) | ((((uint32_t)y >> sh) & 1u) << 1) | ((((uint32_t)z >> sh) & 1u) << 2);
-            const uint32_t valid = n.y & 0xFFu, bit = 1u << oct;
-            child = n.x + (uint32_t)__popc(valid & (bit - 1u));
-            if (sh) n = t.nodes[child];
-        }
-        h.payload = child;
+        h.payload = svo_leaf_of_hit(t, l3, (uint32_t)x, (uint32_t)y, (uint32_t)z);
     }
     return h;
 }
@@ -1302,16 +1339,7 @@ __device__ __forceinline__ Hit trace_svo_blocks_asm(const SvoDev &t, const Ray &
         // the hit cell again from cur, which the lane has not changed since (the same two operations the loop did)
         const uint32_t x = (uint32_t)(int)(h.cx + r.ex), y = (uint32_t)(int)(h.cy + r.ey), z = (uint32_t)(int)(h.cz + r.ez);
         h.index = x + res * (y + res * z);
-        uint2 n = t.nodes[hitl3];
-        uint32_t child = 0;
-        #pragma unroll
-        for (int sh = 2; sh >= 0; --sh) {
-            const uint32_t oct = ((x >> sh) & 1u) | (((y >> sh) & 1u) << 1) | (((z >> sh) & 1u) << 2);
-            const uint32_t valid = n.y & 0xFFu, bit = 1u << oct;
-            child = n.x + (uint32_t)__popc(valid & (bit - 1u));
-            if (sh) n = t.nodes[child];
-        }
-        h.payload = child;
+        h.payload = svo_leaf_of_hit(t, hitl3, x, y, z);
     }
     return h;
 }
@@ -2119,8 +2147,11 @@ __global__ void __launch_bounds__(256) build_svo_table(const uint2 *nodes, int d
 // per 4^3 octant in octant order, bit x&3 | (y&3)<<2 | (z&3)<<4 set iff that voxel is a leaf -- the dense bricks'
 // layout.  A word is zero exactly when the octant's valid bit is clear, PROVIDED no stored node is empty; a valid
 // child without children would end the oracle's walk one level further down (a smaller empty cell), so such a
-// tree sets *bad and keeps the node-chain traversal.
-__global__ void __launch_bounds__(256) build_svo_blocks(const uint2 *nodes, uint32_t l3_first, uint32_t l3_count, uint64_t *blocks, uint32_t *bad)
+// tree sets *bad and keeps the node-chain traversal.  word_base: per word the leaf index of its first voxel in tree
+// order; bad[1] is set when the leaves under some word are NOT stored one after the other in that order (then a hit's
+// leaf is found by walking down from the level-3 node, svo_leaf_by_walk).
+__global__ void __launch_bounds__(256) build_svo_blocks(const uint2 *nodes, uint32_t l3_first, uint32_t l3_count, uint64_t *blocks,
+                                                        uint32_t *word_base, uint32_t *bad)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= l3_count) return;
@@ -2129,6 +2160,8 @@ __global__ void __launch_bounds__(256) build_svo_blocks(const uint2 *nodes, uint
     if ((n3.y >> 8) & 0xFFu) *bad = 1u;                                  // leaves above level 1
     for (uint32_t o4 = 0; o4 < 8; ++o4) {
         uint64_t word = 0;
+        uint32_t first_leaf = 0, next_leaf = 0;
+        bool any = false;
         if (valid3 & (1u << o4)) {
             const uint2 n2 = nodes[n3.x + (uint32_t)__popc(valid3 & ((1u << o4) - 1u))];
             const uint32_t valid2 = n2.y & 0xFFu;
@@ -2138,6 +2171,9 @@ __global__ void __launch_bounds__(256) build_svo_blocks(const uint2 *nodes, uint
                 const uint2 n1 = nodes[n2.x + (uint32_t)__popc(valid2 & ((1u << o2) - 1u))];
                 const uint32_t leaf = (n1.y >> 8) & 0xFFu;
                 if (!leaf || leaf != (n1.y & 0xFFu)) *bad = 1u;
+                if (!any) { first_leaf = n1.x; any = true; }
+                else if (n1.x != next_leaf) bad[1] = 1u;
+                next_leaf = n1.x + (uint32_t)__popc(leaf);
                 for (uint32_t o1 = 0; o1 < 8; ++o1) {
                     if (!(leaf & (1u << o1))) continue;
                     const uint32_t x = ((o2 & 1u) << 1) | (o1 & 1u), y = (((o2 >> 1) & 1u) << 1) | ((o1 >> 1) & 1u),
@@ -2147,6 +2183,7 @@ __global__ void __launch_bounds__(256) build_svo_blocks(const uint2 *nodes, uint
             }
         }
         blocks[(size_t)j * 8 + o4] = word;
+        word_base[(size_t)j * 8 + o4] = first_leaf;
     }
 }
 
