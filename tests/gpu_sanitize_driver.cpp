@@ -227,6 +227,12 @@ int main(int argc, char **argv)
         CHECK(volly_gpu_scene_info(sc, 8) == 3);           // the packed frame kernel and its queue of parked rays
         if (render_all_ways(sc, 64, 16)) return 1;
         volly_gpu_free(sc);
+        // a side that is no multiple of 16: occupancy levels padded to whole regions, a 25^3 beam grid
+        CHECK(volume_gpu_generate_noise(0, 100, 2u, 1u << 24, &sc) == VOLLY_OK);
+        CHECK(volly_gpu_scene_info(sc, 8) == 3 && volly_gpu_scene_info(sc, 14) == 2 && volly_gpu_scene_info(sc, 15) == 2);
+        CHECK(volly_gpu_scene_info(sc, 17) > 0 && volly_gpu_scene_info(sc, 17) < 100 * 100 * 100);
+        if (render_all_ways(sc, 100, 25)) return 1;
+        volly_gpu_free(sc);
         CHECK(volume_gpu_generate_noise(0, 30, 1u, 1u << 24, &sc) == VOLLY_E_ARG);
         std::vector<float> tri(9 * 1000);
         for (size_t i = 0; i < tri.size(); ++i) tri[i] = (float)((i * 2654435761u) % 1000u) / 500.0f - 1.0f;
