@@ -478,6 +478,7 @@ def main():
                 "l2_read_hit_rate": pmc["l2_read_hit_rate"], "waves_per_simd": pmc["waves_per_simd"],
                 "active_lanes_avg": pmc["active_lanes_avg"], "ta_busy_frac": pmc.get("ta_busy_frac"),
                 "pmc_kernel_avg_ms": pmc["kernel_avg_ms"],
+                "rocprof_kernel_avg_ms_timed_steps": pmc.get("kernel_timed_avg_ms"),   # the trace's launches of the timed steps: agrees with roofline.kernel_avg_ms
                 "lib_sha16": pmc.get("lib_sha16"), "git_head": pmc.get("git_head"), "source": pmc["source"]}
         out["roofline"] = roof
 

@@ -29,7 +29,7 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 summary, table = {}, []
-import subprocess
+import subprocess, re
 try:
     git_head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     if subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "volume-renderer_amd", "include"], capture_output=True, text=True).stdout.strip():
@@ -55,6 +55,30 @@ for kdir in sorted(glob.glob(os.path.join(src, "*", ""))):
             total_ns += float(r["TotalDurationNs"])
     if kern_ms is not None and first_calls:
         kern_ms = total_ns / first_calls / 1e6
+    # the same kernel launch by launch (rocprofv3's kernel trace): the stats file's average includes the warm-up launches,
+    # which run before the clocks have ramped; bench.py's HIP events bracket the timed steps only, so the figure that
+    # must agree with `roofline.kernel_avg_ms` is the average over the launches of the timed steps
+    timed_ms, per_launch = None, []
+    traces = glob.glob(os.path.join(kdir, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    args_txt = open(os.path.join(kdir, "bench_args.txt")).read() if os.path.exists(os.path.join(kdir, "bench_args.txt")) else ""
+    m_steps, m_warm = re.search(r"--steps (\d+)", args_txt), re.search(r"--warmup (\d+)", args_txt)
+    n_steps, n_warm = int(m_steps.group(1)) if m_steps else 20, int(m_warm.group(1)) if m_warm else 5
+    if traces:
+        rows = sorted(csv.DictReader(open(traces[0])), key=lambda r: int(r["Start_Timestamp"]))
+        for r in rows:
+            ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            if "render_frames" in r["Kernel_Name"]:
+                per_launch.append(ms)
+            elif "continue_rays_packed" in r["Kernel_Name"] and per_launch:
+                per_launch[-1] += ms
+        timed = per_launch[n_warm:n_warm + n_steps]
+        if len(timed) == n_steps:
+            timed_ms = sum(timed) / n_steps
+        with open(os.path.join(dst, f"{key}_kernel_launches.csv"), "w") as o:
+            o.write("launch,kernel_ms,what\n")
+            for i, ms in enumerate(per_launch):
+                what = "warm-up" if i < n_warm else "timed step" if i < n_warm + n_steps else "after the timed region (plane sums for the bench line)"
+                o.write(f"{i + 1},{ms:.4f},{what}\n")
     bench = {}
     try:
         bench = json.loads(open(os.path.join(kdir, "bench_line.json")).readline())
@@ -94,6 +118,8 @@ for kdir in sorted(glob.glob(os.path.join(src, "*", ""))):
     if cycles and g("TA_BUSY_avr"):
         d["ta_busy_frac"] = round(g("TA_BUSY_avr") / cycles, 3)
     d["kernel_avg_ms"] = round(kern_ms, 4) if kern_ms else None
+    d["kernel_timed_avg_ms"] = round(timed_ms, 4) if timed_ms else None      # launches of the timed steps only
+    d["hip_event_kernel_avg_ms_same_run"] = bench.get("roofline", {}).get("kernel_avg_ms")
     d["kernel"] = kname if kern_ms else None
     if kern_ms and "hbm_bytes_per_launch" in d:
         d["hbm_real_gbs_under_rocprof"] = round(d["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, 1)
