@@ -10,7 +10,7 @@ rows = [("c0", "**headline**: dragon 1024³ octree, 16 × 4K, beam (orbit, radiu
         ("c0_inside", "headline scene, camera inside the grid (orbit radius 0.25), beam"), ("c0_inside_naive", "… naive"),
         ("c0_fill", "headline scene, model fills the frame (orbit radius 0.5), beam"), ("c0_fill_naive", "… naive"),
         ("c1", "config 1: teapot 128³, 64 × 640×480"), ("c2", "config 2: dragon 512³, 64 × 1080p, beam"), ("c2_naive", "config 2, naive"),
-        ("c3", "config 3: noise 1024³ dense, 2 × 4K, p = 1/256"), ("c3_naive", "config 3, naive"), ("c3_p64", "config 3, p = 1/64"), ("c3_p1024", "config 3, p = 1/1024"),
+        ("c3", "config 3: noise 1024³ dense, 2 × 4K, p = 1/256"), ("c3_naive", "config 3, naive"), ("c3_v16", "config 3, 16 × 4K per launch (the headline's launch size)"), ("c3_p64", "config 3, p = 1/64"), ("c3_p1024", "config 3, p = 1/1024"),
         ("c4", "config 4: galleon 2048³ octree, one 8K frame, 1 GPU"), ("c5", "config 5: stratocaster / dragon 1024³ alternating, 64 × 1080p")]
 print("| Workload | Mrays/s (1 GPU, wall) | round 2 | kernel ms / launch | hit fraction | steps per ray (low + target) | `roofline.frac` (VALU) | algorithmic GB/s (of 8 TB/s) | CPU oracle, 1 core |")
 print("|---|---|---|---|---|---|---|---|---|")

@@ -27,6 +27,7 @@ run c2 --config 2 || exit 1
 run c2_naive --config 2 --mode naive --no-cpu-baseline --no-end-to-end || exit 1
 run c3 --config 3 --no-end-to-end || exit 1
 run c3_naive --config 3 --mode naive --no-end-to-end || exit 1
+run c3_v16 --config 3 --views 16 --no-cpu-baseline --no-end-to-end || exit 1
 run c3_p64 --config 3 --noise-log2-inv-p 6 --no-end-to-end || exit 1
 run c3_p1024 --config 3 --noise-log2-inv-p 10 --no-end-to-end || exit 1
 run c4 --config 4 || exit 1

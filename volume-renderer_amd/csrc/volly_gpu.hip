@@ -202,13 +202,18 @@ void choose_frame_kernel(volly_gpu_scene *s)
     const uint64_t cells = (uint64_t)s->target.sx * (uint64_t)s->target.sy * (uint64_t)s->target.sz;
     s->packed = !s->is_svo && host_grid_is_regular(s->target) && !s->target.use_regions && s->target.n_filled * 600 >= cells;
     if (const char *e = std::getenv("VOLLY_PACKED")) s->packed = !s->is_svo && host_grid_is_regular(s->target) && std::atoi(e) != 0;
-    s->pack_budget = 48;
+    // round length: in a volume whose rays run long (p <= 1/128) the pooling between passes packs well enough and a
+    // compaction inside the first passes only costs (96: one round per 96-iteration pass); in a denser one the rays of a
+    // block end early and the rounds pay (profiles/r03_ab/r03_c3_tune4.log: p = 1/32 .. 1/512)
+    s->pack_budget = s->target.n_filled * 96 <= cells ? 96 : 48;
     if (const char *e = std::getenv("VOLLY_PACK_BUDGET")) s->pack_budget = (uint32_t)std::max(std::atoi(e), 1);
     // passes (render_chunk): the rays still under way after VOLLY_PACK_PASS_LEN iterations are parked and pooled into
     // full workgroups for the next pass; VOLLY_PACK_PASSES=1: one pass to the end
     s->pack_passes = 6;
     if (const char *e = std::getenv("VOLLY_PACK_PASSES")) s->pack_passes = std::min(std::max(std::atoi(e), 1), 32);
-    s->pack_lookahead_from = 3;      // passes from this one on (the first is 0) run the look-ahead loop
+    // passes from this one on (the first is 0) run the look-ahead loop: the passes that hold few, long rays -- the
+    // fourth and later at p >= 1/128, the sixth and later in sparser volumes, whose middle passes are still full
+    s->pack_lookahead_from = s->target.n_filled * 192 <= cells ? 5 : 3;
     if (const char *e = std::getenv("VOLLY_PACK_LOOKAHEAD_FROM")) s->pack_lookahead_from = std::max(std::atoi(e), 1);
     s->pack_pass_len = 96;
     if (const char *e = std::getenv("VOLLY_PACK_PASS_LEN")) s->pack_pass_len = (uint32_t)std::max(std::atoi(e), 1);
