@@ -136,15 +136,17 @@ def launch_ranks(n):
     return worst
 
 
-def pmc_entry(key, rays_per_launch, sha):
+def pmc_entry(key, rays_per_launch, src_sha):
     """Counter figures of this workload's dominant kernel from a separate rocprofv3 --pmc run
     (profiles/run_pmc.sh + profiles/summarize.py), or None when that run was not made, had another
-    shape, or was taken on another build of the library (the file records the library's hash)."""
+    shape, or was taken on a library built from other sources.  The tie is the hash of the kernel
+    sources that the library records at build time (volly_gpu_build_info, src_sha16): the hash of the
+    .so file itself changes from one build of the same sources to the next (hipcc's temporary names)."""
     try:
         e = json.load(open(PMC_FILE)).get(key)
     except Exception:
         return None
-    if not e or e.get("rays_per_launch") != rays_per_launch or not sha or e.get("lib_sha16") != sha:
+    if not e or e.get("rays_per_launch") != rays_per_launch or not src_sha or e.get("src_sha16") != src_sha:
         return None
     return e
 
@@ -427,6 +429,7 @@ def main():
     }
     out["config"]["camera"] = args.camera
     out["lib_sha16"] = lib_sha16()
+    out["src_sha16"] = vra.gpu.build_info().get("src_sha16")
     if assembled_ok is not None:
         out["config"]["assembled_frame_equals_single_gpu_frame"] = assembled_ok
     if per_rank_ms is not None:
@@ -458,7 +461,7 @@ def main():
                 "lane_ops_per_launch": int(ops_per_launch), "ops_per_step": OPS_PER_STEP, "ops_per_ray": OPS_PER_RAY,
                 "hbm_algorithmic_bytes_per_launch": int(alg_per_launch), "hbm_algorithmic_gbs": round(alg_gbs, 2),
                 "hbm_algorithmic_frac_of_8tbs": round(alg_gbs / HBM_PEAK_GBS, 5)}
-        sha = lib_sha16()
+        sha = out["src_sha16"]
         key = f"config{args.config}:{args.mode}" + ("" if args.camera == "orbit" else f":{args.camera}") + \
               ("" if args.noise_log2_inv_p == 8 else f":p{args.noise_log2_inv_p}")
         pmc = pmc_entry(key, rays_per_launch, sha) if not split or world == 1 else None
@@ -479,7 +482,7 @@ def main():
                 "active_lanes_avg": pmc["active_lanes_avg"], "ta_busy_frac": pmc.get("ta_busy_frac"),
                 "pmc_kernel_avg_ms": pmc["kernel_avg_ms"],
                 "rocprof_kernel_avg_ms_timed_steps": pmc.get("kernel_timed_avg_ms"),   # the trace's launches of the timed steps: agrees with roofline.kernel_avg_ms
-                "lib_sha16": pmc.get("lib_sha16"), "git_head": pmc.get("git_head"), "source": pmc["source"]}
+                "src_sha16": pmc.get("src_sha16"), "lib_sha16": pmc.get("lib_sha16"), "git_head": pmc.get("git_head"), "source": pmc["source"]}
         out["roofline"] = roof
 
     # ---- end to end (untimed relative to `value`): the synchronous host-buffer entry point

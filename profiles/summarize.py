@@ -5,8 +5,8 @@ profiles/<tag>/:
   pmc_summary.csv          per-launch mean of every counter of the frame kernel, one block per workload,
                            followed by the derived figures
   and profiles/pmc_<tag>.json, which bench.py attaches to its JSON line (roofline.traffic, `measured`) --
-  each entry stamped with the hash of the library the counters were taken on (lib_sha16, from the bench line
-  of the trace run) and the git head at the time of condensing; bench.py ignores entries of another build.
+  each entry stamped with the source hash recorded in the library the counters were taken on (src_sha16, from
+  the bench line of the trace run; lib_sha16 = that .so file's own hash) and the git head at the time of condensing; bench.py ignores entries of another build.
 
 Derived figures (per launch of vk::render_frames<...>; a launch of vk::render_frames_packed includes the
 vk::continue_rays_packed passes that follow it):
@@ -127,7 +127,8 @@ for kdir in sorted(glob.glob(os.path.join(src, "*", ""))):
     if g("SQ_INSTS_VALU"):
         d["valu_insts_per_launch"] = int(g("SQ_INSTS_VALU"))
     # the build the counters were taken on: bench.py drops `measured` when the library it loads has another hash
-    d["lib_sha16"] = bench.get("lib_sha16")
+    d["src_sha16"] = bench.get("src_sha16")      # hash of the kernel sources the library records: what bench.py matches
+    d["lib_sha16"] = bench.get("lib_sha16")      # hash of the .so file of that run (differs between builds of one source)
     d["git_head"] = git_head
     d["rays_per_launch"] = cfg.get("rays_per_step")
     d["workload"] = cfg.get("workload")
