@@ -136,6 +136,37 @@ def launch_ranks(n):
     return worst
 
 
+def init_ranks(dist, torch, backend, rank, world, local_rank):
+    """The process group of the N ranks: RCCL (torch's "nccl" backend) as the contract asks, probed with one
+    all-reduce.  If RCCL cannot be brought up on this node -- an exception from the set-up or from the probe, on
+    every rank alike, since the probe needs all of them -- the ranks fall back to gloo rather than lose the run:
+    the default workload has no collective on its data path (barrier and max-over-ranks timing only), and the
+    split mode's gather then goes through host memory, which the JSON line says ("backend").  Returns the
+    backend in use and a note for the JSON line (None when nothing went wrong)."""
+    import datetime
+    note = None
+    if backend == "nccl":
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=300))
+            probe = torch.ones(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"probe all-reduce returned {probe.item()} on {world} ranks")
+            return "nccl", None
+        except Exception as e:
+            note = f"nccl failed ({type(e).__name__}: {str(e)[:160]}), control collectives on gloo"
+            print(f"bench.py rank {rank}: {note}", file=sys.stderr, flush=True)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    return "gloo", note
+
+
 def pmc_entry(key, rays_per_launch, src_sha):
     """Counter figures of this workload's dominant kernel from a separate rocprofv3 --pmc run
     (profiles/run_pmc.sh + profiles/summarize.py), or None when that run was not made, had another
@@ -173,20 +204,23 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: start it as `python bench.py --gpus N` "
               f"or under torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr)
         sys.exit(2)
+    # stdout carries ONE line, the JSON line: RCCL prints a version banner and gloo its connection lines to file
+    # descriptor 1 from native code, so from here on descriptor 1 is stderr and the JSON line goes to the saved one
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
     if args.force_device is not None:
         local_rank = args.force_device
+    backend_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if not args.dry_run:
             torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        args.backend, backend_note = init_ranks(dist, torch, args.backend, rank, world, local_rank)
         if dist.get_world_size() != args.gpus:
             print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
@@ -198,9 +232,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"metric": "primary Mrays/s", "value": None, "unit": "Mrays/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "dry_run": True,
-                              "max_over_ranks_probe": float(t.item())}), flush=True)
+            line = {"metric": "primary Mrays/s", "value": None, "unit": "Mrays/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                    "backend": args.backend if world > 1 else None, "backend_note": backend_note,
+                    "max_over_ranks_probe": float(t.item())}
+            print(json.dumps(line), file=json_out, flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -432,6 +468,10 @@ def main():
     out["src_sha16"] = vra.gpu.build_info().get("src_sha16")
     if assembled_ok is not None:
         out["config"]["assembled_frame_equals_single_gpu_frame"] = assembled_ok
+    if world > 1:
+        out["backend"] = "rccl (torch nccl)" if args.backend == "nccl" else "gloo"
+        if backend_note:
+            out["backend_note"] = backend_note
     if per_rank_ms is not None:
         mean_ms = sum(per_rank_ms) / len(per_rank_ms)
         out["per_rank_kernel_ms"] = per_rank_ms
@@ -548,7 +588,7 @@ def main():
                                "sample": f"{n_cpu} frame(s) of a timed step of {names[0]} ({n_cpu * rows * W} rays), "
                                          f"scalar C oracle, gcc -O3 -mavx -ffp-contract=off, {cpu_s:.1f} s"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     for g in gpus:
         g.close()
     if world > 1:
