@@ -1,6 +1,7 @@
 """bench.py's ranks when RCCL cannot be brought up (collected late: it depends on how RCCL refuses, and the round's
 end runs pytest -x -- a surprise here must not hide the parity tests)."""
 import os
+import signal
 import sys
 
 import pytest
@@ -17,12 +18,16 @@ def test_bench_falls_back_to_gloo_when_rccl_refuses_the_ranks():
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--scene", "teapot.off", "--res", "128",
+           "--width", "640", "--height", "360", "--views", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--scene", "teapot.off", "--res", "128",
-                            "--width", "640", "--height", "360", "--views", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                           capture_output=True, text=True, timeout=240, env=env)
+        stdout, stderr = p.communicate(timeout=240)
     except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)                 # the launcher and its ranks: nothing of this run stays on the GPU
+        p.communicate()
         pytest.skip("RCCL neither started nor refused two ranks on one GPU within 4 minutes: nothing to fall back from here")
+    r = subprocess.CompletedProcess(cmd, p.returncode, stdout, stderr)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
