@@ -84,6 +84,10 @@ def parse():
                     help="noise scene: a voxel is filled with probability 2^-n (config 3: 8 = 1/256; sweeps 6 and 10)")
     ap.add_argument("--split", action="store_true", default=None,
                     help="one frame per step split into row bands over the ranks + gather to rank 0 (config 4)")
+    ap.add_argument("--split-rows", type=int, default=-1,
+                    help="single-frame split: stripes of this many rows dealt round-robin over the ranks; -1 = the smallest multiple "
+                         "of 8 (at least 16) that gives a rank at most 64 stripes, i.e. one launch per step; 0 = contiguous row bands "
+                         "(SURVEY 8e's first form: 50-65 %% load imbalance at 4-8 ranks, profiles/split_imbalance.py)")
     ap.add_argument("--mode", choices=["beam", "naive"], default="beam",
                     help="beam = raycast_beamOpt (the reference's live path); naive = traversal from the camera")
     ap.add_argument("--camera", choices=["orbit", "startup", "inside", "fill"], default="orbit",
@@ -309,14 +313,36 @@ def main():
     W, H, B = args.width, args.height, args.views
     naive = args.mode == "naive"
     split = bool(args.split)
-    if split:
+    if args.split_rows < 0:      # one launch takes 64 sub-rectangles
+        args.split_rows = max(16, -(-args.height // (64 * world * 8)) * 8)
+    stripes = split and args.split_rows > 0 and world > 1       # (one rank renders the whole frame in one piece)
+    gatherer = None
+    if stripes:
+        # one frame, stripes of --split-rows rows dealt round-robin: a rank's planes are its stripes stacked (the
+        # frame-major layout of ONE call over its sub-rectangles); rgba8 is the gatherer's own send buffer
+        B = 1
+        S = args.split_rows
+        mine = vra.shard.stripe_rows(H, rank, world, S)
+        rows = sum(r for _, r in mine)
+        gatherer = vra.shard.StripeGatherer(H, W, rank, world, torch.int32, coll_dev, S)
+        slots = gatherer.send.shape[0]
+        plane_shape = (slots, S, W)
+    elif split:
         B = 1
         y0, rows = vra.shard.band_rows(H, rank, world)
+        plane_shape = (B, rows, W)
     else:
         y0, rows = 0, H
+        plane_shape = (B, rows, W)
     plane_names = ("rgba8", "hit_index", "steps_lo", "steps_hi", "depth")
-    planes = {p: torch.empty((B, rows, W), dtype=torch.float32 if p == "depth" else torch.int32, device=dev)
+    planes = {p: torch.empty(plane_shape, dtype=torch.float32 if p == "depth" else torch.int32, device=dev)
               for p in plane_names}
+    if stripes:       # the planes of rows nobody renders (unused slots, the rest of a shorter last stripe) read as misses with no steps
+        for p in ("steps_lo", "steps_hi"):
+            planes[p].zero_()
+        planes["hit_index"].fill_(-1)
+        if coll_dev == dev:
+            planes["rgba8"] = gatherer.send     # rendered in place: no copy in front of the collective
     ptrs = {p: t.data_ptr() for p, t in planes.items()}
     stream = torch.cuda.current_stream(dev)
 
@@ -338,6 +364,8 @@ def main():
                 frames[i] = vra.frame_from_camera(view, (0.0, 0.0, 0.0), size_hi, size_lo, W, H, naive=naive)
         else:
             frames = vra.orbit_frames(ks, orbit_n, size_hi, size_lo, W, H, radius=args.radius, naive=naive)
+        if stripes:   # (full, tail): one call over the stripes of full height, one for a shorter last stripe
+            return vra.shard.stripe_frames(frames[0], rank, world, args.split_rows)
         if split:
             frames[0] = frames[0].band(y0, rows)
         return frames
@@ -345,13 +373,34 @@ def main():
     all_frames = [step_frames(s) for s in range(args.warmup + args.steps)]
     assembled = [None]
     # send buffer, receive list and the assembled frame are allocated once, outside the timed loop
-    gatherer = vra.shard.BandGatherer(H, W, rank, world, torch.int32, coll_dev) if split else None
+    if split and not stripes:
+        gatherer = vra.shard.BandGatherer(H, W, rank, world, torch.int32, coll_dev)
+
+    def render(s, into):
+        """one step's launches: planes at the device pointers `into`"""
+        g = gpus[s % len(gpus)]
+        if not stripes:
+            g.render_device(all_frames[s], into, stream=stream.cuda_stream)
+            return
+        full, tail = all_frames[s]
+        if len(full):
+            g.render_device(full, into, stream=stream.cuda_stream)
+        if tail is not None:      # behind the full stripes' slots
+            off = len(full) * args.split_rows * W * 4
+            g.render_device(tail, {p: a + off for p, a in into.items()}, stream=stream.cuda_stream)
+
+    def gather_frame():
+        if stripes:
+            if coll_dev != dev:
+                gatherer.send.copy_(planes["rgba8"])
+            return gatherer.gather(dist)
+        band = planes["rgba8"][0]
+        return gatherer.gather(band if coll_dev == dev else band.cpu(), dist)
 
     def run(s):
-        gpus[s % len(gpus)].render_device(all_frames[s], ptrs, stream=stream.cuda_stream)
+        render(s, ptrs)
         if split:      # frame assembly on rank 0: the one collective of the path (RCCL gather over xGMI)
-            band = planes["rgba8"][0]
-            assembled[0] = gatherer.gather(band if coll_dev == dev else band.cpu(), dist)
+            assembled[0] = gather_frame()
 
     for s in range(args.warmup):
         run(s)
@@ -385,20 +434,20 @@ def main():
     # ---- per-rank figures: kernel time of every rank, and for the split the gather alone ----
     per_rank_ms, gather_ms = None, None
     if world > 1:
-        mine = torch.tensor([kern_ms / max(launches, 1)], dtype=torch.float64, device=coll_dev)
+        # per step: a rank that also holds the frame's shorter last stripe launches twice per step
+        mine = torch.tensor([kern_ms / args.steps if split else kern_ms / max(launches, 1)], dtype=torch.float64, device=coll_dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         per_rank_ms = [round(float(v.item()), 4) for v in every]
     if split and world > 1:            # untimed: the collective by itself, bands already rendered
-        band = planes["rgba8"][0] if coll_dev == dev else planes["rgba8"][0].cpu()
         for _ in range(2):
-            gatherer.gather(band, dist)
+            gather_frame()
         torch.cuda.synchronize(dev)
         dist.barrier()
         tg = time.perf_counter()
         reps = 10
         for _ in range(reps):
-            gatherer.gather(band, dist)
+            gather_frame()
         torch.cuda.synchronize(dev)
         dist.barrier()
         tgm = torch.tensor([(time.perf_counter() - tg) / reps * 1e3], dtype=torch.float64, device=coll_dev)
@@ -419,9 +468,12 @@ def main():
     group = max(1, min(args.steps, int(48e9 // (12 * rays_per_launch))))
     for first in range(args.warmup, args.warmup + args.steps, group):
         steps_here = range(first, min(first + group, args.warmup + args.steps))
-        keep = [{p: torch.empty_like(planes[p]) for p in need} for _ in steps_here]
+        if stripes:      # slots and rows nobody renders must read as misses with no steps
+            keep = [{p: (torch.full_like(planes[p], -1) if p == "hit_index" else torch.zeros_like(planes[p])) for p in need} for _ in steps_here]
+        else:
+            keep = [{p: torch.empty_like(planes[p]) for p in need} for _ in steps_here]
         for s, k in zip(steps_here, keep):
-            gpus[s % len(gpus)].render_device(all_frames[s], dict(ptrs, **{p: t.data_ptr() for p, t in k.items()}), stream=stream.cuda_stream)
+            render(s, dict(ptrs, **{p: t.data_ptr() for p, t in k.items()}))
         for k in keep:
             acc[0] += k["steps_lo"].sum(dtype=torch.int64)
             acc[1] += k["steps_hi"].sum(dtype=torch.int64)
@@ -442,7 +494,8 @@ def main():
 
     rays_per_step = (H * W) if split else (B * H * W * world)       # whole job, all ranks
     mrays = rays_per_step * args.steps / elapsed / 1e6
-    par = (f"one frame split into {world} row bands + gather of rgba8 to rank 0" if split
+    par = (f"one frame split into stripes of {args.split_rows} rows dealt round-robin over {world} ranks + gather of rgba8 to rank 0" if stripes
+           else f"one frame split into {world} row bands + gather of rgba8 to rank 0" if split
            else f"view-parallel x{world}, scene replicated, no collective")
     label = "north-star target" if args.config == 0 else f"BASELINE config {args.config}"
     if args.scene == "noise" and args.noise_log2_inv_p != 8:
@@ -478,7 +531,7 @@ def main():
         out["load_imbalance"] = round(max(per_rank_ms) / mean_ms - 1.0, 4) if mean_ms > 0 else None
     if gather_ms is not None:
         out["gather_ms"] = gather_ms
-        out["gather_bytes_per_peer"] = int(vra.shard.band_rows(H, 0, world)[1] * W * 4)
+        out["gather_bytes_per_peer"] = int(gatherer.send.numel() * 4)
     if prepare is not None:
         out["config"]["scene_prepared_on_device"] = prepare
     if launches:

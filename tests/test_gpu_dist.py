@@ -88,15 +88,18 @@ def test_two_ranks_render_bands_on_the_gpu_and_gather(tmp_path):
     assert ok == "1" and int(lit) > 500
 
 
-def test_bench_split_rehearsal_reports_per_rank_figures():
+@pytest.mark.parametrize("split_rows", [-1, 8, 0])      # stripes chosen by bench.py (16 rows here), 8-row stripes with a 1-row last one, row bands
+def test_bench_split_rehearsal_reports_per_rank_figures(split_rows):
     """bench.py's single-frame split (config 4's path) with two gloo ranks sharing this box's GPU: every rank builds its
-    replica with volume_gpu_voxelize, renders its row band, the bands are gathered through pre-allocated buffers, and
-    the JSON line carries what SURVEY 8e asks the split to report -- per-rank kernel times, load imbalance, the gather
-    alone -- and says that the assembled frame equals the frame one GPU renders."""
+    replica with volume_gpu_voxelize, renders its share of the rows -- stripes dealt round-robin, or one contiguous
+    band -- the shares are gathered through pre-allocated buffers, and the JSON line carries what SURVEY 8e asks the
+    split to report -- per-rank kernel times, load imbalance, the gather alone -- and says that the assembled frame
+    equals the frame one GPU renders."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--force-device", "0", "--split",
+                        "--split-rows", str(split_rows),
                         "--scene", "teapot.off", "--res", "128", "--width", "640", "--height", "361", "--steps", "3", "--warmup", "1"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -105,6 +108,10 @@ def test_bench_split_rehearsal_reports_per_rank_figures():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["assembled_frame_equals_single_gpu_frame"] is True
+    assert out["config"]["rays_per_step"] == 640 * 361
     assert len(out["per_rank_kernel_ms"]) == 2 and all(ms > 0 for ms in out["per_rank_kernel_ms"])
-    assert out["load_imbalance"] >= 0 and out["gather_ms"] > 0 and out["gather_bytes_per_peer"] == 181 * 640 * 4
+    assert out["load_imbalance"] >= 0 and out["gather_ms"] > 0
+    # what travels per peer: the tallest band, or rank 0's stripes (12 of 16 rows, 23 of 8 rows)
+    assert out["gather_bytes_per_peer"] == {0: 181, -1: 12 * 16, 8: 23 * 8}[split_rows] * 640 * 4
+    assert ("stripes" in out["config"]["parallelism"]) == (split_rows != 0)
     assert "device" in out["data"]                      # replicas built by volume_gpu_voxelize on every rank
