@@ -143,7 +143,8 @@ def launch_ranks(n):
 def init_ranks(dist, torch, backend, rank, world, local_rank):
     """The process group of the N ranks: RCCL (torch's "nccl" backend) as the contract asks, probed with one
     all-reduce.  If RCCL cannot be brought up on this node -- an exception from the set-up or from the probe, on
-    every rank alike, since the probe needs all of them -- the ranks fall back to gloo rather than lose the run:
+    every rank alike, since the probe needs all of them; a rank that fails alone leaves the others waiting for RCCL's
+    own timeout first -- the ranks fall back to gloo rather than lose the run:
     the default workload has no collective on its data path (barrier and max-over-ranks timing only), and the
     split mode's gather then goes through host memory, which the JSON line says ("backend").  Returns the
     backend in use and a note for the JSON line (None when nothing went wrong)."""
@@ -152,7 +153,7 @@ def init_ranks(dist, torch, backend, rank, world, local_rank):
     if backend == "nccl":
         try:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                    timeout=datetime.timedelta(seconds=300))
+                                    timeout=datetime.timedelta(seconds=120))
             probe = torch.ones(1, device=torch.device("cuda", local_rank))
             dist.all_reduce(probe)
             torch.cuda.synchronize()
