@@ -65,7 +65,9 @@ def test_single_rank_dry_run():
 def test_ranks_fall_back_to_gloo_when_rccl_cannot_start():
     """Without a GPU the "nccl" (RCCL) process group cannot be brought up: every rank sees the failure, the
     ranks meet again on gloo, and the JSON line names the backend that ran and why."""
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    # (GPUs hidden, so that the failure is the same on every rank wherever this runs)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300,
+                       env=_clean_env(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
     assert r.returncode == 0, r.stderr[-2000:]
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 2 and out["backend"] == "gloo" and "nccl failed" in out["backend_note"]
