@@ -83,7 +83,7 @@ def parse():
     ap.add_argument("--noise-log2-inv-p", type=int, default=8,
                     help="noise scene: a voxel is filled with probability 2^-n (config 3: 8 = 1/256; sweeps 6 and 10)")
     ap.add_argument("--split", action="store_true", default=None,
-                    help="one frame per step split into row bands over the ranks + gather to rank 0 (config 4)")
+                    help="one frame per step split over the ranks (stripes of rows, see --split-rows) + gather to rank 0 (config 4)")
     ap.add_argument("--split-rows", type=int, default=-1,
                     help="single-frame split: stripes of this many rows dealt round-robin over the ranks; -1 = the smallest multiple "
                          "of 8 (at least 16) that gives a rank at most 64 stripes, i.e. one launch per step; 0 = contiguous row bands "
